@@ -1,0 +1,365 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+What it does
+  * imports the reference's model code through synthetic parent packages (the
+    reference's own ``__init__`` files eagerly import uninstalled dependencies;
+    ``lightning`` / ``omegaconf`` get two in-process stand-in modules that the
+    arithmetic never touches) -- SURVEY.md section 8(c);
+  * fills reference modules with ``oracle.eo_vae_cpu.det_fill`` (closed form,
+    no weight files), runs them on seeded inputs and stores inputs + outputs
+    as small ``.npz`` fixtures (data only -- no reference source is stored);
+  * as a by-product asserts that the oracle restatement agrees with the
+    reference on every fixture (so a broken oracle can never be committed).
+
+MS-SSIM has no reference-side fixture: ``torchmetrics`` is not installed
+("parity unpinned").
+"""
+
+from __future__ import annotations
+
+import ast
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import eo_vae_cpu as O  # noqa: E402
+
+
+def import_reference():
+    for name, rel in [('eo_vae', 'eo_vae'), ('eo_vae.models', 'eo_vae/models'),
+                      ('eo_vae.models.modules', 'eo_vae/models/modules')]:
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, rel)]
+        sys.modules[name] = m
+    lt = types.ModuleType('lightning')
+    lt.LightningModule = torch.nn.Module
+    sys.modules['lightning'] = lt
+    oc = types.ModuleType('omegaconf')
+    oc.OmegaConf = object
+    sys.modules['omegaconf'] = oc
+    R = types.SimpleNamespace()
+    R.model = importlib.import_module('eo_vae.models.model')
+    R.layers = importlib.import_module('eo_vae.models.modules.layers')
+    R.dyn = importlib.import_module('eo_vae.models.modules.dynamic_conv')
+    R.dist = importlib.import_module('eo_vae.models.modules.distributions')
+    R.vae = importlib.import_module('eo_vae.models.new_autoencoder')
+    return R
+
+
+def ref_class_from_source(path, cls_name, ns):
+    """Execute ONE class definition of a reference script that cannot be imported
+    as a whole (top-level imports of uninstalled packages)."""
+    tree = ast.parse(open(path).read())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
+    mod = ast.Module(body=[node], type_ignores=[])
+    exec(compile(mod, path, 'exec'), ns)
+    return ns[cls_name]
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-30
+    assert err <= tol * max(ref, 1.0), f'oracle != reference for {what}: {err} (ref max {ref})'
+    return err
+
+
+def hashed(shape, salt, scale=1.0):
+    n = int(np.prod(shape))
+    return (O._hash_uniform(n, salt).reshape(shape) * (scale * 12 ** 0.5)).float()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f'  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def grads_of(module, out, gy, x=None):
+    module.zero_grad()
+    if x is not None and x.grad is not None:
+        x.grad = None
+    out.backward(gy)
+    g = {k: npy(p.grad) for k, p in module.named_parameters()}
+    return g
+
+
+def per_op(R):
+    print('per-op fixtures')
+    # ---- ResnetBlock (with and without nin_shortcut), layers.py:53-114
+    for tag, cin, cout, hw in [('res_same', 32, 32, 16), ('res_proj', 32, 64, 16)]:
+        ref = R.layers.ResnetBlock(cin, cout)
+        mine = O.ResnetBlock(cin, cout)
+        O.det_fill(ref, seed=11)
+        mine.load_state_dict(ref.state_dict())
+        x = hashed((2, cin, hw, hw), 101, 1.0).requires_grad_(True)
+        gy = hashed((2, cout, hw, hw), 102, 1.0)
+        y = ref(x)
+        gp = grads_of(ref, y, gy, x)
+        gx = npy(x.grad)
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = mine(x2)
+        gp2 = grads_of(mine, y2, gy)
+        close(y2, y, 1e-5, tag + '.y')
+        close(x2.grad, gx, 1e-4, tag + '.gx')
+        for k in gp:
+            close(gp2[k], gp[k], 1e-3, f'{tag}.g[{k}]')  # k.bias grad is analytically 0: pure round-off
+        save('op_' + tag, x=npy(x), gy=npy(gy), y=npy(y), gx=gx,
+             **{'g.' + k: v for k, v in gp.items()})
+    # ---- AttnBlock, layers.py:117-142
+    for tag, c, hw in [('attn_8', 64, 8), ('attn_16', 64, 16)]:
+        ref, mine = R.layers.AttnBlock(c), O.AttnBlock(c)
+        O.det_fill(ref, seed=12, gain=2.0)
+        mine.load_state_dict(ref.state_dict())
+        x = hashed((2, c, hw, hw), 111, 1.0).requires_grad_(True)
+        gy = hashed((2, c, hw, hw), 112, 1.0)
+        y = ref(x)
+        gp = grads_of(ref, y, gy, x)
+        gx = npy(x.grad)
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = mine(x2)
+        gp2 = grads_of(mine, y2, gy)
+        close(y2, y, 1e-5, tag + '.y')
+        close(x2.grad, gx, 1e-4, tag + '.gx')
+        for k in gp:
+            close(gp2[k], gp[k], 1e-3, f'{tag}.g[{k}]')  # k.bias grad is analytically 0: pure round-off
+        save('op_' + tag, x=npy(x), gy=npy(gy), y=npy(y), gx=gx,
+             **{'g.' + k: v for k, v in gp.items()})
+    # ---- Downsample / Upsample, layers.py:25-50
+    for tag, cls_r, cls_o, hw in [('down', R.layers.Downsample, O.Downsample, 16),
+                                  ('up', R.layers.Upsample, O.Upsample, 8)]:
+        ref, mine = cls_r(32), cls_o(32)
+        O.det_fill(ref, seed=13)
+        mine.load_state_dict(ref.state_dict())
+        x = hashed((2, 32, hw, hw), 121, 1.0).requires_grad_(True)
+        y = ref(x)
+        gy = hashed(tuple(y.shape), 122, 1.0)
+        gp = grads_of(ref, y, gy, x)
+        gx = npy(x.grad)
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = mine(x2)
+        gp2 = grads_of(mine, y2, gy)
+        close(y2, y, 1e-5, tag + '.y')
+        close(x2.grad, gx, 1e-4, tag + '.gx')
+        for k in gp:
+            close(gp2[k], gp[k], 1e-3, f'{tag}.g[{k}]')  # k.bias grad is analytically 0: pure round-off
+        save('op_' + tag, x=npy(x), gy=npy(gy), y=npy(y), gx=gx,
+             **{'g.' + k: v for k, v in gp.items()})
+    # ---- dynamic convs at FULL hyper-network size (wv_planes 256, 4 layers), dynamic_conv.py
+    ref_in = R.dyn.DynamicConv(wv_planes=256, inter_dim=128, kernel_size=3, stride=1, padding=1,
+                               embed_dim=128, num_layers=4)
+    ref_out = R.dyn.DynamicConv_decoder(wv_planes=256, inter_dim=128, kernel_size=3, stride=1,
+                                        padding=1, embed_dim=128, num_layers=4)
+    my_in = O.DynamicConv(wv_planes=256, embed_dim=128, num_layers=4)
+    my_out = O.DynamicConv_decoder(wv_planes=256, embed_dim=128, num_layers=4)
+    O.det_fill(ref_in, seed=14)
+    O.det_fill(ref_out, seed=15)
+    my_in.load_state_dict(ref_in.state_dict())
+    my_out.load_state_dict(ref_out.state_dict())
+    ref_in.eval(), ref_out.eval(), my_in.eval(), my_out.eval()
+    arrays = {}
+    for mod, wl in O.WAVELENGTHS.items():
+        wvs = torch.tensor(wl)
+        c = len(wl)
+        x = hashed((1, c, 12, 12), 131 + c, 1.0)
+        h = hashed((1, 128, 12, 12), 141 + c, 1.0)
+        with torch.no_grad():
+            y_in = ref_in(x, wvs)
+            y_out = ref_out(h, wvs)
+            w_in, b_in = ref_in.get_distillation_weight(wvs)  # same tensors forward() convolves with
+            w_out = ref_out.weight
+            m_w_in, m_b_in = my_in.generate(wvs)
+            m_w_out, m_b_out = my_out.generate(wvs)
+            close(m_w_in, w_in, 1e-5, f'dyn_in.w[{mod}]')
+            close(m_b_in, b_in, 1e-5, f'dyn_in.b[{mod}]')
+            close(m_w_out, w_out, 1e-5, f'dyn_out.w[{mod}]')
+            close(my_in(x, wvs), y_in, 1e-5, f'dyn_in.y[{mod}]')
+            close(my_out(h, wvs), y_out, 1e-5, f'dyn_out.y[{mod}]')
+        # decoder bias (scaled twice): recover from a zero input
+        with torch.no_grad():
+            b_out = ref_out(torch.zeros(1, 128, 4, 4), wvs)[0, :, 0, 0]
+            close(m_b_out, b_out, 1e-5, f'dyn_out.b[{mod}]')
+        arrays.update({f'{mod}.w_in': npy(w_in), f'{mod}.b_in': npy(b_in),
+                       f'{mod}.w_out': npy(w_out), f'{mod}.b_out': npy(b_out),
+                       f'{mod}.x': npy(x), f'{mod}.h': npy(h),
+                       f'{mod}.y_in': npy(y_in), f'{mod}.y_out': npy(y_out)})
+    save('op_dynconv', **arrays)
+    # ---- posterior, distributions.py:19-102
+    moments = hashed((2, 64, 8, 8), 151, 2.0)
+    moments[0, 32:, 0, 0] = 40.0   # exercise the clamp(-30, 20)
+    moments[1, 32:, 1, 1] = -50.0
+    eps = hashed((2, 32, 8, 8), 152, 1.0)
+    ref_p = R.dist.DiagonalGaussianDistribution(moments)
+    my_p = O.DiagonalGaussianDistribution(moments)
+    sample = ref_p.mean + ref_p.std * eps  # distributions.py:44-46 with the noise injected
+    close(my_p.sample(eps), sample, 1e-6, 'posterior.sample')
+    close(my_p.kl(), ref_p.kl(), 1e-6, 'posterior.kl')
+    save('op_posterior', moments=npy(moments), eps=npy(eps), sample=npy(sample),
+         kl=npy(ref_p.kl()), mode=npy(ref_p.mode()))
+
+
+def whole_models(R):
+    print('tiny whole-model fixtures')
+    cfg = O.model_cfg(**O.TINY)
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    mine = O.build_vae(cfg)
+    O.det_fill(ref, seed=21)
+    assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+    mine.load_state_dict(ref.state_dict())
+    out = {}
+    for mod in ['S2RGB', 'S1RTC', 'S2L2A']:
+        wvs = torch.tensor(O.WAVELENGTHS[mod])
+        x = O.synthetic_batch(2, len(wvs), 64, seed=1234 + len(wvs))
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            rec = ref.reconstruct(x, wvs)
+            lat = ref.encode_to_latent(x, wvs)
+            spat = ref.encode_spatial_normalized(x, wvs)
+            mom = ref.encode(x, wvs).parameters
+            dec = ref.decode_spatial_normalized(spat, wvs)
+            close(mine.reconstruct(x, wvs), rec, 1e-4, f'tiny.recon[{mod}]')
+            close(mine.encode_to_latent(x, wvs), lat, 1e-4, f'tiny.latent[{mod}]')
+            close(mine.encode_spatial_normalized(x, wvs), spat, 1e-4, f'tiny.spatial[{mod}]')
+            close(mine.decode_spatial_normalized(spat, wvs), dec, 1e-4, f'tiny.dec[{mod}]')
+        out.update({f'{mod}.x': npy(x), f'{mod}.recon': npy(rec), f'{mod}.latent': npy(lat),
+                    f'{mod}.spatial': npy(spat), f'{mod}.moments': npy(mom), f'{mod}.dec': npy(dec)})
+    save('tiny_eval', **out)
+
+    # ---- train-mode forward/backward + 3 optimiser steps (L1, clip 1.0, warmup schedule)
+    print('tiny train trajectory')
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    ref.train(), mine.train()
+    base_lr, final_lr = 1e-3, 2e-4
+    params_r = [p for p in ref.encoder.parameters()] + [p for p in ref.decoder.parameters()]
+    opt_r = torch.optim.Adam(params_r, lr=base_lr)
+    # new_autoencoder.py:568-581 with steps_per_epoch shrunk so 3 steps cross the warm-up
+    sch_r = R.vae.get_cosine_schedule_with_warmup(opt_r, num_warmup_steps=2, num_training_steps=6,
+                                                  base_lr=base_lr, final_lr=final_lr)
+    st = O.TrainState(mine, base_lr=base_lr, final_lr=final_lr, warmup_epochs=1, decay_end_epoch=3,
+                      clip_grad=1.0, steps_per_epoch=2)
+    loss_o = O.EOConsistencyLoss(pixel_weight=1.0, rec_loss_type='l1')
+    traj = {}
+    for step in range(3):
+        x = O.synthetic_batch(2, len(wvs), 64, seed=500 + step)
+        eps = hashed((2, 32, 8, 8), 600 + step, 1.0)
+        # reference forward with the posterior noise injected (distributions.py:44-46)
+        torch.manual_seed(0)
+        post = ref.encode(x, wvs)
+        z = post.mean + post.std * eps
+        from einops import rearrange
+        zs = rearrange(z, '... c (i pi) (j pj) -> ... (c pi pj) i j', pi=2, pj=2)
+        recon = ref.decode(ref._normalize_latent(zs), wvs)
+        opt_r.zero_grad()
+        loss = torch.nn.functional.l1_loss(recon, x)   # consistency_loss.py:418
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params_r, 1.0)
+        lr = opt_r.param_groups[0]['lr']
+        if step == 0:
+            names = [k for k, _ in list(ref.encoder.named_parameters())]
+            gnorms = {('encoder.' + k): p.grad.norm().item() for k, p in ref.encoder.named_parameters()}
+            gnorms.update({('decoder.' + k): p.grad.norm().item() for k, p in ref.decoder.named_parameters()})
+            traj['grad_names'] = np.array(list(gnorms.keys()))
+            traj['grad_norms'] = np.array(list(gnorms.values()), dtype=np.float64)
+            traj['recon0'] = npy(recon)
+            traj['kl0'] = npy(post.kl())
+        opt_r.step()
+        sch_r.step()
+        l2, logs, gn2 = st.step(loss_o, x, wvs, noise=eps)
+        close(l2, loss, 2e-5, f'traj.loss[{step}]')
+        close(gn2, gn, 1e-3, f'traj.gnorm[{step}]')
+        assert abs(logs['train/lr'] - lr) < 1e-12, (logs['train/lr'], lr)
+        traj[f'x{step}'] = npy(x)
+        traj[f'eps{step}'] = npy(eps)
+        traj[f'loss{step}'] = np.float64(loss.item())
+        traj[f'gnorm{step}'] = np.float64(gn.item())
+        traj[f'lr{step}'] = np.float64(lr)
+    sd_r, sd_m = ref.state_dict(), mine.state_dict()
+    for k in sd_r:
+        # Adam turns round-off-only gradients (e.g. a conv bias feeding a GroupNorm, whose true
+        # gradient is 0) into +-lr steps, so parameters agree to ~sum(lr), not to 1e-4
+        close(sd_m[k].float(), sd_r[k].float(), 2e-3, f'traj.param[{k}]')
+    traj['bn_running_mean'] = npy(sd_r['bn.running_mean'])
+    traj['bn_running_var'] = npy(sd_r['bn.running_var'])
+    traj['bn_batches'] = np.int64(sd_r['bn.num_batches_tracked'].item())
+    probe = ['encoder.down.0.block.0.conv1.weight', 'decoder.up.1.block.0.nin_shortcut.weight',
+             'decoder.conv_out.weight_generator.fc_weight.weight', 'encoder.mid.attn_1.q.weight']
+    for k in probe:
+        traj['final.' + k] = npy(sd_r[k]).reshape(-1)[:64]
+    save('tiny_train', **traj)
+
+
+def full_size(R):
+    print('full-size cfg1 fixture (B=2, S2RGB, 256x256) -- takes ~20 s')
+    cfg = O.model_cfg()
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    O.det_fill(ref, seed=31)
+    ref.eval()
+    n_params = sum(p.numel() for p in ref.encoder.parameters()) + sum(p.numel() for p in ref.decoder.parameters())
+    assert n_params == 95514145, n_params
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    with torch.no_grad():
+        rec = ref.reconstruct(x, wvs)
+        spat = ref.encode_spatial_normalized(x, wvs)
+    mine = O.build_vae(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine.eval()
+    with torch.no_grad():
+        close(mine.reconstruct(x, wvs), rec, 1e-4, 'full.recon')
+        close(mine.encode_spatial_normalized(x, wvs), spat, 1e-4, 'full.spatial')
+    save('full_cfg1', x_checksum=np.float64(x.double().sum().item()),
+         recon_sub=npy(rec[:, :, ::8, ::8]), spatial_sub=npy(spat[:, :, ::2, ::2]),
+         recon_stats=np.array([[rec[:, c].mean().item(), rec[:, c].std().item(),
+                                rec[:, c].min().item(), rec[:, c].max().item()] for c in range(3)]),
+         n_params=np.int64(n_params), n_keys=np.int64(len(ref.state_dict())),
+         keys=np.array(list(ref.state_dict().keys())))
+
+
+def running_stats():
+    print('RunningStatsButFast fixture')
+    ns = {'torch': torch, 'nn': torch.nn}
+    Ref = ref_class_from_source(os.path.join(REF, 'encode_latents.py'), 'RunningStatsButFast', ns)
+    ref = Ref((32,), [0, 2, 3])
+    mine = O.RunningStats(32)
+    arrays = {}
+    for i in range(3):
+        z = hashed((4, 32, 8, 8), 700 + i, 1.0 + i) + 0.3 * i
+        ref(z)
+        mine.update(z)
+        arrays[f'z{i}'] = npy(z)
+    for k in ['mean', 'var', 'std', 'min', 'max', 'count']:
+        close(getattr(mine, k), getattr(ref, k), 1e-6, 'stats.' + k)
+        arrays[k] = npy(getattr(ref, k))
+    save('running_stats', **arrays)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    R = import_reference()
+    torch.manual_seed(0)  # dynamic_conv.py:7-8 reseeds the global RNG at import (quirk q1)
+    per_op(R)
+    whole_models(R)
+    running_stats()
+    full_size(R)
+    print('all fixtures written; oracle == reference on every one of them')

@@ -1,0 +1,196 @@
+"""CPU: the oracle restatement (oracle/eo_vae_cpu.py) against the golden vectors that
+tests/golden/gen_golden.py produced by running the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eo_vae_cpu as O
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def assert_close(a, b, rtol, what=''):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1.0)
+    assert err <= rtol * scale, f'{what}: max err {err:.3e} > {rtol:.1e} * {scale:.3e}'
+
+
+def _module_case(golden, name, module, seed, gain=1.0):
+    g = golden(name)
+    O.det_fill(module, seed=seed, gain=gain)
+    x = T(g['x']).requires_grad_(True)
+    y = module(x)
+    assert_close(y, g['y'], 1e-5, name + '.y')
+    y.backward(T(g['gy']))
+    assert_close(x.grad, g['gx'], 1e-4, name + '.gx')
+    for k, p in module.named_parameters():
+        assert_close(p.grad, g['g.' + k], 1e-3, f'{name}.g[{k}]')
+
+
+@pytest.mark.parametrize('name,cin,cout', [('op_res_same', 32, 32), ('op_res_proj', 32, 64)])
+def test_resnet_block(golden, name, cin, cout):
+    _module_case(golden, name, O.ResnetBlock(cin, cout), seed=11)
+
+
+@pytest.mark.parametrize('name', ['op_attn_8', 'op_attn_16'])
+def test_attn_block(golden, name):
+    _module_case(golden, name, O.AttnBlock(64), seed=12, gain=2.0)
+
+
+def test_down_up(golden):
+    _module_case(golden, 'op_down', O.Downsample(32), seed=13)
+    _module_case(golden, 'op_up', O.Upsample(32), seed=13)
+
+
+def test_dynamic_convs(golden):
+    g = golden('op_dynconv')
+    din = O.DynamicConv(wv_planes=256, embed_dim=128, num_layers=4).eval()
+    dout = O.DynamicConv_decoder(wv_planes=256, embed_dim=128, num_layers=4).eval()
+    O.det_fill(din, seed=14)
+    O.det_fill(dout, seed=15)
+    for mod, wl in O.WAVELENGTHS.items():
+        wvs = torch.tensor(wl)
+        with torch.no_grad():
+            w, b = din.generate(wvs)
+            assert_close(w, g[f'{mod}.w_in'], 1e-5, mod + '.w_in')
+            assert_close(b, g[f'{mod}.b_in'], 1e-5, mod + '.b_in')
+            w, b = dout.generate(wvs)
+            assert_close(w, g[f'{mod}.w_out'], 1e-5, mod + '.w_out')
+            assert_close(b, g[f'{mod}.b_out'], 1e-5, mod + '.b_out')   # scaled twice (q4)
+            assert_close(din(T(g[f'{mod}.x']), wvs), g[f'{mod}.y_in'], 1e-5, mod + '.y_in')
+            assert_close(dout(T(g[f'{mod}.h']), wvs), g[f'{mod}.y_out'], 1e-5, mod + '.y_out')
+
+
+def test_posterior(golden):
+    g = golden('op_posterior')
+    p = O.DiagonalGaussianDistribution(T(g['moments']))
+    assert_close(p.sample(T(g['eps'])), g['sample'], 1e-6, 'sample')
+    assert_close(p.kl(), g['kl'], 1e-6, 'kl')
+    assert_close(p.mode(), g['mode'], 0.0, 'mode')
+
+
+@pytest.fixture(scope='module')
+def tiny():
+    m = O.build_vae(O.model_cfg(**O.TINY))
+    O.det_fill(m, seed=21)
+    return m
+
+
+def test_tiny_eval(golden, tiny):
+    g = golden('tiny_eval')
+    tiny.eval()
+    for mod in ['S2RGB', 'S1RTC', 'S2L2A']:
+        wvs = torch.tensor(O.WAVELENGTHS[mod])
+        x = T(g[f'{mod}.x'])
+        # the synthetic generator must regenerate the stored input bit-for-bit
+        assert torch.equal(x, O.synthetic_batch(2, len(wvs), 64, seed=1234 + len(wvs)))
+        assert_close(tiny.reconstruct(x, wvs), g[f'{mod}.recon'], 1e-4, mod + '.recon')
+        assert_close(tiny.encode_to_latent(x, wvs), g[f'{mod}.latent'], 1e-4, mod + '.latent')
+        sp = tiny.encode_spatial_normalized(x, wvs)
+        assert_close(sp, g[f'{mod}.spatial'], 1e-4, mod + '.spatial')
+        assert_close(tiny.encode(x, wvs).parameters, g[f'{mod}.moments'], 1e-4, mod + '.moments')
+        assert_close(tiny.decode_spatial_normalized(T(g[f'{mod}.spatial']), wvs), g[f'{mod}.dec'],
+                     1e-4, mod + '.dec')
+
+
+def test_tiny_train_trajectory(golden):
+    g = golden('tiny_train')
+    m = O.build_vae(O.model_cfg(**O.TINY))
+    O.det_fill(m, seed=21)
+    m.train()
+    st = O.TrainState(m, base_lr=1e-3, final_lr=2e-4, warmup_epochs=1, decay_end_epoch=3,
+                      clip_grad=1.0, steps_per_epoch=2)
+    loss_fn = O.EOConsistencyLoss(pixel_weight=1.0, rec_loss_type='l1')
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    for step in range(3):
+        if step == 0:
+            recon, post = m(T(g['x0']), wvs, noise=T(g['eps0']))
+            assert_close(recon, g['recon0'], 1e-4, 'recon0')
+            assert_close(post.kl(), g['kl0'], 1e-5, 'kl0')
+            loss = torch.nn.functional.l1_loss(recon, T(g['x0']))
+            loss.backward()
+            named = {('encoder.' + k): p for k, p in m.encoder.named_parameters()}
+            named.update({('decoder.' + k): p for k, p in m.decoder.named_parameters()})
+            tot = float(np.sqrt((g['grad_norms'] ** 2).sum()))
+            clip = min(1.0, 1.0 / (float(g['gnorm0']) + 1e-6))   # fixture norms are post-clip
+            for k, ref in zip(g['grad_names'], g['grad_norms']):
+                got = named[str(k)].grad.norm().item() * clip
+                assert abs(got - ref) <= 1e-3 * max(ref, 1e-3 * tot), (k, got, ref)
+            m.zero_grad()
+            # undo the running-stat update of this probing forward
+            O.det_fill(m.bn, seed=0)
+            sd = O.build_vae(O.model_cfg(**O.TINY))
+            O.det_fill(sd, seed=21)
+            m.bn.load_state_dict(sd.bn.state_dict())
+        loss, logs, gn = st.step(loss_fn, T(g[f'x{step}']), wvs, noise=T(g[f'eps{step}']))
+        assert abs(loss.item() - g[f'loss{step}']) <= 1e-4 * abs(g[f'loss{step}']), step  # loss scalars: 1e-4
+        assert abs(gn.item() - g[f'gnorm{step}']) <= 1e-3 * g[f'gnorm{step}']
+        assert abs(logs['train/lr'] - g[f'lr{step}']) < 1e-12
+    assert g['lr0'] == 0.0  # quirk q6: LR factor 0 at step 0
+    sd = m.state_dict()
+    assert_close(sd['bn.running_mean'], g['bn_running_mean'], 1e-4, 'bn.running_mean')
+    assert_close(sd['bn.running_var'], g['bn_running_var'], 1e-4, 'bn.running_var')
+    assert int(sd['bn.num_batches_tracked']) == int(g['bn_batches'])
+    for k in [k for k in g if k.startswith('final.')]:
+        assert_close(sd[k[6:]].reshape(-1)[:64], g[k], 2e-3, k)
+
+
+def test_running_stats(golden):
+    g = golden('running_stats')
+    rs = O.RunningStats(32)
+    for i in range(3):
+        rs.update(T(g[f'z{i}']))
+    for k in ['mean', 'var', 'std', 'min', 'max', 'count']:
+        assert_close(getattr(rs, k), g[k], 1e-6, k)
+
+
+def test_state_dict_contract(golden):
+    """363 keys / 95 514 145 trainable parameters."""
+    g = golden('full_cfg1')
+    m = O.build_vae(O.model_cfg())
+    assert [str(k) for k in g['keys']] == list(m.state_dict().keys())
+    n = sum(p.numel() for p in m.encoder.parameters()) + sum(p.numel() for p in m.decoder.parameters())
+    assert n == int(g['n_params']) == 95514145
+
+
+def test_full_cfg1_reconstruct(golden):
+    """BASELINE config 1: S2RGB 3-ch 256x256, batch 2, reconstruct() on CPU."""
+    g = golden('full_cfg1')
+    m = O.build_vae(O.model_cfg()).eval()
+    O.det_fill(m, seed=31)
+    torch.set_num_threads(8)
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    assert abs(x.double().sum().item() - float(g['x_checksum'])) < 1e-6
+    rec = m.reconstruct(x, wvs)
+    assert_close(rec[:, :, ::8, ::8], g['recon_sub'], 1e-4, 'recon')
+    assert_close(m.encode_spatial_normalized(x, wvs)[:, :, ::2, ::2], g['spatial_sub'], 1e-4, 'spatial')
+
+
+# ---- MS-SSIM: PARITY UNPINNED (torchmetrics absent) -> known-answer properties ----
+
+def test_msssim_properties():
+    x = O.synthetic_batch(2, 4, 192, seed=5)
+    y = x + 0.1 * torch.randn(x.shape, generator=torch.Generator().manual_seed(6))
+    assert abs(O.msssim(x, x).item() - 1.0) < 1e-6            # identical inputs -> 1
+    v = O.msssim(y, x).item()
+    assert 0.0 < v < 1.0
+    assert abs(O.msssim(x, y).item() - v) < 1e-6              # symmetric
+    perm = torch.tensor([1, 0])
+    assert abs(O.msssim(y[perm], x[perm]).item() - v) < 1e-6  # batch-order invariant
+    taps = O.gaussian_taps()
+    assert taps.numel() == 11 and abs(taps.sum().item() - 1) < 1e-6   # kernel_size=5 is ignored (q5)
+    # one scale, constant images: mu = value, sigma = 0 -> ssim = (2ab+c1)/(a^2+b^2+c1), cs = 1
+    a, b = torch.full((1, 1, 32, 32), 2.0), torch.full((1, 1, 32, 32), 3.0)
+    c1, c2 = (0.01 * 6) ** 2, (0.03 * 6) ** 2
+    ssim, cs = O._ssim_cs(a, b, taps, c1, c2)
+    # fp32 cancellation in E[x^2]-mu^2 against c2=0.0324 limits this to ~2e-4
+    assert abs(ssim.item() - (12 + c1) / (13 + c1)) < 5e-4 and abs(cs.item() - 1) < 5e-4
+    # uncorrelated images saturate the loss at 1 with zero gradient (SURVEY 8d cfg3 note)
+    z = torch.randn(1, 2, 192, 192, generator=torch.Generator().manual_seed(7)).requires_grad_(True)
+    w = torch.randn(1, 2, 192, 192, generator=torch.Generator().manual_seed(8))
+    val = O.msssim(z, -z.detach())
+    assert val.item() == 0.0
