@@ -1,0 +1,19 @@
+// C-ABI housekeeping: thread-local error text + version probe.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void eovae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+const char* eovae_last_error(void) { return g_err; }
+int eovae_abi_version(void) { return 1; }
+const char* eovae_target_arch(void) { return "gfx950"; }
+}

@@ -1,0 +1,54 @@
+// Shared helpers for the eo_vae_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define EOVAE_OK 0
+#define EOVAE_ERR_ARG (-1)
+#define EOVAE_ERR_LAUNCH (-2)
+#define EOVAE_ERR_UNSUPPORTED (-3)
+
+// thread-local last-error text, exported through eovae_last_error()
+void eovae_set_error(const char* fmt, ...);
+
+#define EOVAE_CHECK_ARG(cond, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      eovae_set_error(__VA_ARGS__);           \
+      return EOVAE_ERR_ARG;                   \
+    }                                         \
+  } while (0)
+
+#define EOVAE_CHECK_LAUNCH(name)                                               \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      eovae_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+      return EOVAE_ERR_LAUNCH;                                                 \
+    }                                                                          \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// wave64 butterfly sums
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}

@@ -1,0 +1,283 @@
+// GroupNorm(32 groups, eps 1e-6, affine) fused with the swish that follows it in the
+// reference (layers.py:61-63,78-80,91-92,106-108; model.py:159-161,193-194,295-297,349-350):
+//     y = silu( (x - mean_g) * rstd_g * gamma_c + beta_c )        (silu optional: AttnBlock norm)
+// NCHW fp32: one (n, group) is a contiguous run of cpg*HW floats (up to 1 MB at 4 x 256^2), so
+// statistics are a pure streaming reduction: float4 loads, per-thread fp32 partials, wave64
+// shuffle trees, cross-wave/cross-block combine in double.  Memory-bound (HBM roofline).
+#include "eovae_common.h"
+
+namespace {
+
+constexpr int GN_SPLIT_ELEMS = 16384;  // elements per stats block
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+
+// stage 1: partial (sum, sumsq) per (n,g) slice -> part[ng][split][2] (double)
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x,
+                                                         double* __restrict__ part, size_t gsize,
+                                                         int nsplit) {
+  const int ng = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const size_t per = (gsize + nsplit - 1) / nsplit;
+  const size_t beg = (size_t)sp * per;
+  size_t end = beg + per;
+  if (end > gsize) end = gsize;
+  const float* p = x + (size_t)ng * gsize;
+  float s = 0.f, q = 0.f;
+  // gsize is a multiple of 4 whenever HW is; fall back to scalar otherwise
+  if ((gsize & 3) == 0 && (per & 3) == 0) {
+    for (size_t i = beg + 4 * threadIdx.x; i < end; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(p + i);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (size_t i = beg + threadIdx.x; i < end; i += 256) {
+      float v = p[i];
+      s += v;
+      q += v * v;
+    }
+  }
+  __shared__ double red[8];
+  double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = ds; red[4 + w] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((size_t)ng * nsplit + sp) * 2 + 0] = red[0] + red[1] + red[2] + red[3];
+    part[((size_t)ng * nsplit + sp) * 2 + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// stage 2: combine partials -> stats[ng] = (mean, rstd)
+__global__ void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats,
+                                   int NG, int nsplit, double inv_count, float eps) {
+  int ng = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ng >= NG) return;
+  double s = 0, q = 0;
+  for (int i = 0; i < nsplit; ++i) {
+    s += part[((size_t)ng * nsplit + i) * 2];
+    q += part[((size_t)ng * nsplit + i) * 2 + 1];
+  }
+  double mean = s * inv_count;
+  double var = q * inv_count - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * ng] = (float)mean;
+  stats[2 * ng + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// stage 3: normalise + affine (+ silu); grid.x = N*C planes x chunks
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ stats,
+                                                       float* __restrict__ y, int C, int HW, int cpg,
+                                                       int chunks) {
+  const int plane = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = plane % C, n = plane / C;
+  const int ng = n * (C / cpg) + c / cpg;
+  const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
+  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+  const size_t base = (size_t)plane * HW;
+  const int per = (HW + chunks - 1) / chunks;
+  const int beg = chunk * per;
+  int end = beg + per;
+  if (end > HW) end = HW;
+  if ((HW & 3) == 0 && (per & 3) == 0) {
+    for (int i = beg + 4 * threadIdx.x; i < end; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      float4 o;
+      o.x = v.x * sc + sh; o.y = v.y * sc + sh; o.z = v.z * sc + sh; o.w = v.w * sc + sh;
+      if (SILU) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+      *reinterpret_cast<float4*>(y + base + i) = o;
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+      float o = x[base + i] * sc + sh;
+      y[base + i] = SILU ? silu_f(o) : o;
+    }
+  }
+}
+
+// backward pass 1: per (n,c) plane  s1 = sum dz, s2 = sum dz * xhat   (dz = dy * silu'(z))
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ stats,
+                                                            double* __restrict__ sums, int C, int HW,
+                                                            int cpg) {
+  const int plane = blockIdx.x;
+  const int c = plane % C, n = plane / C;
+  const int ng = n * (C / cpg) + c / cpg;
+  const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
+  const float g = gamma[c], b = beta[c];
+  const size_t base = (size_t)plane * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    float xh = (x[base + i] - mean) * rstd;
+    float dz = dy[base + i];
+    if (SILU) {
+      float z = xh * g + b;
+      float sg = 1.f / (1.f + __expf(-z));
+      dz *= sg * (1.f + z * (1.f - sg));
+    }
+    s1 += dz;
+    s2 += dz * xh;
+  }
+  __shared__ double red[8];
+  double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = d1; red[4 + w] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sums[2 * (size_t)plane] = red[0] + red[1] + red[2] + red[3];
+    sums[2 * (size_t)plane + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// backward pass 2a: dgamma/dbeta[c] = sum_n sums[n][c]; group means m1,m2 per (n,g)
+__global__ void gn_bwd_finalize_kernel(const double* __restrict__ sums,
+                                       const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ gm, int N,
+                                       int C, int cpg, double inv_count) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < C) {
+    double a = 0, b = 0;
+    for (int n = 0; n < N; ++n) {
+      a += sums[2 * ((size_t)n * C + t)];
+      b += sums[2 * ((size_t)n * C + t) + 1];
+    }
+    dbeta[t] = (float)a;
+    dgamma[t] = (float)b;
+  }
+  int G = C / cpg;
+  if (t < N * G) {
+    int n = t / G, g = t % G;
+    double m1 = 0, m2 = 0;
+    for (int j = 0; j < cpg; ++j) {
+      int c = g * cpg + j;
+      m1 += sums[2 * ((size_t)n * C + c)] * gamma[c];
+      m2 += sums[2 * ((size_t)n * C + c) + 1] * gamma[c];
+    }
+    gm[2 * t] = (float)(m1 * inv_count);
+    gm[2 * t + 1] = (float)(m2 * inv_count);
+  }
+}
+
+// backward pass 2b: dx = rstd * (dz*gamma - m1 - xhat*m2) (+ dx_add)
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ stats, const float* __restrict__ gm,
+    const float* __restrict__ dx_add, float* __restrict__ dx, int C, int HW, int cpg, int chunks) {
+  const int plane = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = plane % C, n = plane / C;
+  const int ng = n * (C / cpg) + c / cpg;
+  const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
+  const float g = gamma[c], b = beta[c];
+  const float m1 = gm[2 * ng], m2 = gm[2 * ng + 1];
+  const size_t base = (size_t)plane * HW;
+  const int per = (HW + chunks - 1) / chunks;
+  const int beg = chunk * per;
+  int end = beg + per;
+  if (end > HW) end = HW;
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    float xh = (x[base + i] - mean) * rstd;
+    float dz = dy[base + i];
+    if (SILU) {
+      float z = xh * g + b;
+      float sg = 1.f / (1.f + __expf(-z));
+      dz *= sg * (1.f + z * (1.f - sg));
+    }
+    float v = rstd * (dz * g - m1 - xh * m2);
+    if (dx_add) v += dx_add[base + i];
+    dx[base + i] = v;
+  }
+}
+
+int nsplit_for(size_t gsize) {
+  int ns = (int)((gsize + GN_SPLIT_ELEMS - 1) / GN_SPLIT_ELEMS);
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;
+  // keep slices float4-aligned
+  while (ns > 1 && ((gsize + ns - 1) / ns) % 4 != 0) --ns;
+  return ns;
+}
+int chunks_for(int HW) {
+  int c = HW / 4096;
+  if (c < 1) c = 1;
+  if (c > 16) c = 16;
+  while (c > 1 && ((HW + c - 1) / c) % 4 != 0) --c;
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of scratch the forward/backward need (double partials)
+size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G) {
+  size_t gsize = (size_t)(C / G) * HW;
+  size_t fwd = (size_t)N * G * nsplit_for(gsize) * 2 * sizeof(double);
+  size_t bwd = (size_t)N * C * 2 * sizeof(double) + (size_t)N * G * 2 * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+// stats[N*G][2] = (mean, rstd) is written and must be kept for the backward
+int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                      int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream) {
+  EOVAE_CHECK_ARG(x && gamma && beta && y && stats && ws, "gn_silu_fwd: null pointer");
+  EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "gn_silu_fwd: C=%d G=%d", C, G);
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = C / G;
+  const size_t gsize = (size_t)cpg * HW;
+  const int ns = nsplit_for(gsize);
+  double* part = (double*)ws;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats,
+                     N * G, ns, 1.0 / (double)gsize, eps);
+  const int chunks = chunks_for(HW);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(N * C * chunks), dim3(256), 0, st, x, gamma, beta,
+                       stats, y, C, HW, cpg, chunks);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(N * C * chunks), dim3(256), 0, st, x, gamma,
+                       beta, stats, y, C, HW, cpg, chunks);
+  EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd");
+  return EOVAE_OK;
+}
+
+// dx (+= dx_add if given), dgamma, dbeta from the saved stats
+int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
+                      const float* stats, const float* dx_add, float* dx, float* dgamma,
+                      float* dbeta, int N, int C, int HW, int G, int silu, void* ws, void* stream) {
+  EOVAE_CHECK_ARG(x && dy && gamma && beta && stats && dx && dgamma && dbeta && ws,
+                  "gn_silu_bwd: null pointer");
+  EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "gn_silu_bwd: C=%d G=%d", C, G);
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = C / G;
+  double* sums = (double*)ws;
+  float* gm = (float*)(sums + (size_t)N * C * 2);
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(N * C), dim3(256), 0, st, x, dy, gamma, beta,
+                       stats, sums, C, HW, cpg);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(N * C), dim3(256), 0, st, x, dy, gamma,
+                       beta, stats, sums, C, HW, cpg);
+  int nt = C > N * G ? C : N * G;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, st, sums, gamma,
+                     dgamma, dbeta, gm, N, C, cpg, 1.0 / ((double)cpg * HW));
+  const int chunks = chunks_for(HW);
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
+                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
+                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks);
+  EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd");
+  return EOVAE_OK;
+}
+
+}  // extern "C"

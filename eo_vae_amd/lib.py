@@ -1,0 +1,78 @@
+"""ctypes binding of the C-ABI in include/eovae_hip.h (libeovae_hip.so).
+
+The HIP library is the product path: there is NO fallback.  Missing library, missing GPU
+or a non-zero status from any entry point raises -- loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeovae_hip.so')
+
+_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/eovae_hip.h one to one
+SIGNATURES = {
+    'eovae_last_error': (C.c_char_p, []),
+    'eovae_abi_version': (_i, []),
+    'eovae_target_arch': (C.c_char_p, []),
+    'eovae_conv_packed_dims': (_i, [_i, _i, _i, _i, _i, _ip, _ip]),
+    'eovae_conv_pack_weights': (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    'eovae_conv2d_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    'eovae_conv2d_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_conv_unpack_wgrad': (_i, [_p, _p, _i, _i, _i, _p]),
+    'eovae_bias_grad': (_i, [_p, _p, _i, _i, _i, _p]),
+    'eovae_upsample2x_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'eovae_gn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
+    'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+}
+
+_lib = None
+
+
+class EovaeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libeovae_hip.so (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EovaeError(
+            f'{LIB_PATH} is missing: build it with `python -m eo_vae_amd.build` '
+            '(eo_vae_amd has no CPU/PyTorch fallback for its kernels)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().eovae_last_error().decode(errors='replace')
+        raise EovaeError(f'{what} failed (status {rc}): {msg}')
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise EovaeError(f'{what}: tensor is on {t.device}; eo_vae_amd kernels only run on an '
+                         'AMD GPU (no CPU fallback) -- move the model and inputs to "cuda"')
+    if t.dtype != torch.float32:
+        raise EovaeError(f'{what}: dtype {t.dtype} unsupported (fp32 storage)')
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,102 @@
+"""GPU: every HIP kernel against a plain fp32 PyTorch-CPU statement of the same op.
+Tolerances are written per test; fp32 MFMA is an exact fmaf chain, so differences are
+summation-order round-off only."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def hashed(shape, salt, scale=1.0):
+    from oracle.eo_vae_cpu import _hash_uniform
+    n = 1
+    for s in shape:
+        n *= s
+    return (_hash_uniform(n, salt).reshape(shape) * (scale * 12 ** 0.5)).float()
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def ref_conv(x, w, b, mode):
+    if mode == 'normal':
+        return F.conv2d(x, w, b, padding=(w.shape[-1] - 1) // 2)
+    if mode == 'down':
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    return F.conv2d(F.interpolate(x, scale_factor=2.0, mode='nearest'), w, b, padding=1)
+
+
+CONV_CASES = [
+    # n, cin, cout, h, w, ks, mode
+    (2, 32, 32, 16, 16, 3, 'normal'),
+    (1, 128, 128, 32, 32, 3, 'normal'),
+    (2, 3, 128, 24, 40, 3, 'normal'),      # dynamic conv_in shape (ragged tile edges)
+    (2, 128, 3, 24, 40, 3, 'normal'),      # dynamic conv_out shape
+    (1, 13, 128, 9, 33, 3, 'normal'),      # odd sizes, S2L1C channel count
+    (1, 256, 64, 16, 16, 3, 'normal'),     # Cout < tile
+    (2, 64, 192, 16, 16, 1, 'normal'),     # 1x1 shortcut, Cout not a multiple of 128
+    (1, 512, 512, 8, 8, 1, 'normal'),      # attention q/k/v/proj
+    (2, 32, 32, 16, 16, 3, 'down'),
+    (1, 128, 128, 64, 64, 3, 'down'),
+    (2, 32, 32, 8, 8, 3, 'up'),
+    (1, 256, 256, 16, 16, 3, 'up'),
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,ks,mode', CONV_CASES)
+def test_conv2d_fwd_bwd(n, cin, cout, h, w, ks, mode):
+    from eo_vae_amd import ops
+    x = hashed((n, cin, h, w), 1, 1.0)
+    wt = hashed((cout, cin, ks, ks), 2, 1.0 / (cin * ks * ks) ** 0.5)
+    b = hashed((cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, br, mode)
+    res = hashed(tuple(yr.shape), 5, 1.0)
+    rr = res.clone().requires_grad_(True)
+    gy = hashed(tuple(yr.shape), 4, 1.0)
+    (yr + rr).backward(gy)
+    xg, wg, bg, rg = [t.cuda().requires_grad_(True) for t in (x, wt, b, res)]
+    yg = ops.conv2d(xg, wg, bg, rg, mode)
+    yg.backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(yg, yr + rr) < 2e-6
+    assert rel_err(xg.grad, xr.grad) < 1e-5
+    assert rel_err(wg.grad, wr.grad) < 2e-5      # atomically accumulated split-K partial sums
+    assert rel_err(bg.grad, br.grad) < 1e-5
+    assert rel_err(rg.grad, rr.grad) == 0.0
+
+
+GN_CASES = [(2, 32, 8, 8, True), (2, 128, 32, 32, True), (1, 512, 16, 16, False),
+            (2, 64, 9, 7, True), (1, 128, 128, 128, True)]
+
+
+@pytest.mark.parametrize('n,c,h,w,silu', GN_CASES)
+def test_groupnorm_silu(n, c, h, w, silu):
+    from eo_vae_amd import ops
+    x = hashed((n, c, h, w), 11, 2.0) + 0.7
+    g = 1.0 + hashed((c,), 12, 0.2)
+    b = hashed((c,), 13, 0.2)
+    gy = hashed((n, c, h, w), 14, 1.0)
+    xr, gr, br = [t.clone().requires_grad_(True) for t in (x, g, b)]
+    yr = F.group_norm(xr, 32, gr, br, eps=1e-6)
+    if silu:
+        yr = yr * torch.sigmoid(yr)
+    yr.backward(gy)
+    xg, gg, bg = [t.cuda().requires_grad_(True) for t in (x, g, b)]
+    yg = ops.group_norm_silu(xg, gg, bg, 32, 1e-6, silu)
+    yg.backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(yg, yr) < 1e-5
+    assert rel_err(xg.grad, xr.grad) < 2e-5
+    assert rel_err(gg.grad, gr.grad) < 2e-5
+    assert rel_err(bg.grad, br.grad) < 2e-5
+
+
+def test_fails_loudly_on_cpu_tensor():
+    from eo_vae_amd import ops
+    from eo_vae_amd.lib import EovaeError
+    with pytest.raises(EovaeError):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
