@@ -1,0 +1,142 @@
+"""Wavelength-conditioned first/last convolutions (reference: modules/dynamic_conv.py).
+
+The tiny hyper-network (sin-cos embedding -> FCResLayer -> 4-layer post-norm transformer over
+[128 weight tokens | C wave tokens | 1 bias token]) stays on PyTorch-ROCm ops (< 0.3 GFLOP,
+SURVEY.md 2b K14); the convolution with the generated kernel and its three gradients run on
+the HIP implicit-GEMM kernels."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.init as init
+
+from . import ops
+
+
+def get_1d_sincos_pos_embed_from_grid_torch(embed_dim: int, pos: torch.Tensor) -> torch.Tensor:
+    """[M] positions -> [M, D] = [sin(pos*w) | cos(pos*w)], w_d = 10000^(-d/(D/2)) (:37-59)."""
+    assert embed_dim % 2 == 0
+    half = embed_dim // 2
+    omega = torch.arange(half, dtype=torch.float32, device=pos.device) / float(half)
+    omega = 1.0 / 10000 ** omega
+    ang = pos.reshape(-1)[:, None] * omega[None, :]
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+
+
+class FCResLayer(nn.Module):  # :336-366
+    def __init__(self, linear_size: int = 128):
+        super().__init__()
+        self.l_size = linear_size
+        self.w1 = nn.Linear(linear_size, linear_size)
+        self.w2 = nn.Linear(linear_size, linear_size)
+
+    def forward(self, x):
+        return x + F.relu(self.w2(F.relu(self.w1(x))))
+
+
+class TransformerWeightGenerator(nn.Module):  # :62-130
+    _bias_out = None  # encoder flavour: one bias vector of embed_dim
+
+    def __init__(self, input_dim, output_dim, embed_dim, num_heads=4, num_layers=1):
+        super().__init__()
+        layer = nn.TransformerEncoderLayer(d_model=input_dim, nhead=num_heads, activation='gelu',
+                                           norm_first=False, batch_first=False, dropout=0.0)
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_layers,
+                                                         enable_nested_tensor=False)
+        self.fc_weight = nn.Linear(input_dim, output_dim)
+        self.fc_bias = nn.Linear(input_dim, self._bias_out or embed_dim)
+        self.wt_num = 128
+        self.weight_tokens = nn.Parameter(torch.empty(self.wt_num, input_dim))
+        self.bias_token = nn.Parameter(torch.empty(1, input_dim))
+        init.normal_(self.weight_tokens, std=0.02)
+        init.normal_(self.bias_token, std=0.02)
+
+    def _tokens(self, waves):
+        seq = torch.cat([self.weight_tokens, waves, self.bias_token], dim=0)
+        return self.transformer_encoder(seq)  # unbatched [L, d]
+
+    def forward(self, waves):
+        out = self._tokens(waves)
+        return self.fc_weight(out[self.wt_num:-1] + waves), self.fc_bias(out[-1])
+
+
+class TransformerWeightGenerator_decoder(TransformerWeightGenerator):  # :133-183
+    _bias_out = 1
+
+    def forward(self, waves):
+        out = self._tokens(waves)
+        wave_out = out[self.wt_num:-1]
+        bias = self.fc_bias(wave_out + self.bias_token.repeat(waves.shape[0], 1))
+        return self.fc_weight(wave_out + waves), bias
+
+
+def _xavier_linear(m):
+    if isinstance(m, nn.Linear):
+        init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            m.bias.data.fill_(0.01)
+
+
+class _DynamicBase(nn.Module):
+    generator_cls = TransformerWeightGenerator
+
+    def __init__(self, wv_planes, inter_dim=128, kernel_size=3, stride=1, padding=1, embed_dim=128,
+                 num_layers=1, num_heads=4, generator_type='transformer', rank_ratio=4):
+        super().__init__()
+        if generator_type != 'transformer':
+            raise NotImplementedError("only generator_type='transformer' is on the hot path "
+                                      '(configs/eo-vae.yaml)')
+        if kernel_size != 3 or stride != 1 or padding != 1:
+            raise NotImplementedError('dynamic conv: 3x3, stride 1, padding 1 only')
+        self.kernel_size, self.wv_planes, self.embed_dim = kernel_size, wv_planes, embed_dim
+        self._num_kernel = kernel_size * kernel_size * embed_dim
+        self.inter_dim, self.stride, self.padding = inter_dim, stride, padding
+        self.generator_type, self.use_weight_standardization = generator_type, False
+        self.weight_generator = self.generator_cls(wv_planes, self._num_kernel, embed_dim,
+                                                   num_heads=num_heads, num_layers=num_layers)
+        self.scaler = 0.1
+        self.fclayer = FCResLayer(wv_planes)
+        self.weight_generator.apply(_xavier_linear)
+        self.fclayer.apply(_xavier_linear)
+
+    def _raw(self, wvs):
+        waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
+        return self.weight_generator(self.fclayer(waves))
+
+
+class DynamicConv(_DynamicBase):
+    """C -> embed_dim, kernel [E, C, 3, 3] generated per wavelength (:369-535)."""
+
+    def get_distillation_weight(self, wvs_microns):
+        weight, bias = self._raw(wvs_microns)
+        k = self.kernel_size
+        w = weight.view(wvs_microns.size(0), k, k, self.embed_dim).permute(3, 0, 1, 2)
+        return w * self.scaler, bias.view(self.embed_dim) * self.scaler
+
+    def forward(self, img_feat, wvs):
+        w, b = self.get_distillation_weight(wvs)
+        return ops.conv2d(img_feat, w, b, None, 'normal')
+
+
+class DynamicConv_decoder(_DynamicBase):
+    """embed_dim -> C, kernel [C, E, 3, 3]; the bias is scaled by 0.1 twice in forward
+    (:692-697) but once in get_distillation_weight (:659-664) -- reproduced as is."""
+    generator_cls = TransformerWeightGenerator_decoder
+
+    def __init__(self, wv_planes, inter_dim=128, kernel_size=3, stride=1, padding=1, embed_dim=128,
+                 num_layers=2, num_heads=4, generator_type='transformer', rank_ratio=4):
+        super().__init__(wv_planes, inter_dim, kernel_size, stride, padding, embed_dim, num_layers,
+                         num_heads, generator_type, rank_ratio)
+
+    def get_distillation_weight(self, wvs_microns):
+        weight, bias = self._raw(wvs_microns)
+        k = self.kernel_size
+        w = weight.view(wvs_microns.size(0), k, k, self.embed_dim).permute(0, 3, 1, 2)
+        return w * self.scaler, bias.squeeze() * self.scaler
+
+    def forward(self, img_feat, waves):
+        w, b = self.get_distillation_weight(waves)
+        b = (b * self.scaler).reshape(-1)
+        self.weight = w  # read by EOFluxVAE.get_last_layer (:708)
+        return ops.conv2d(img_feat, w, b, None, 'normal')

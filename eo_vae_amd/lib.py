@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libeovae_hip.so')
 
 _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ip = C.POINTER(C.c_int)
+_ll = C.c_longlong
 
 # name -> (restype, argtypes); mirrors include/eovae_hip.h one to one
 SIGNATURES = {
@@ -30,6 +31,23 @@ SIGNATURES = {
     'eovae_gn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
+    'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
+    'eovae_softmax_bwd_rows': (_i, [_p, _p, _ll, _i, _p]),
+    'eovae_attention_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    'eovae_attention_bwd': (_i, [_p] * 9 + [_i, _i, _i, _f, _p]),
+    'eovae_posterior_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    'eovae_posterior_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'eovae_latent_bn_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
+    'eovae_latent_bn_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'eovae_latent_inv': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    'eovae_loss_workspace_bytes': (_sz, []),
+    'eovae_pixel_loss_fwd': (_i, [_p, _p, _sz, _i, _f, _p, _p, _p]),
+    'eovae_pixel_loss_bwd': (_i, [_p, _p, _p, _p, _sz, _i, _f, _p]),
+    'eovae_gradnorm_workspace_bytes': (_sz, []),
+    'eovae_grad_norm': (_i, [_p, _sz, _f, _p, _p, _p]),
+    'eovae_adam_step': (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _p, _f, _p]),
+    'eovae_scale_inplace': (_i, [_p, _sz, _p, _f, _p]),
 }
 
 _lib = None

@@ -1,0 +1,83 @@
+"""Reconstruction / consistency loss on the HIP kernels
+(reference: eo_vae/models/modules/consistency_loss.py:329-483).
+
+On the hot path: pixel term (L1 or Charbonnier) and the scheduled MS-SSIM term, plus an
+opt-in KL term that the reference's training path lacks (default weight 0
+=> identical to the reference).  The SAM / gradient / FFL / DOFA-feature branches are weight-0
+in configs/eo-vae.yaml and out of scope: a non-zero weight raises."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class CharbonnierLoss(nn.Module):  # :12-21
+    def __init__(self, eps=1e-3):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, pred, target):
+        return ops.charbonnier_loss(pred, target, self.eps)
+
+
+class SSIMLoss(nn.Module):
+    """1 - MS-SSIM(data_range=6, gaussian sigma 1.5 => 11 taps, 5 scales) (:24-37)."""
+
+    def __init__(self, channels=12):
+        super().__init__()
+        self.data_range = 6.0
+        self.betas = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+    def forward(self, pred, target):
+        return 1.0 - ops.msssim(pred, target, self.data_range, self.betas)
+
+
+class EOConsistencyLoss(nn.Module):
+    def __init__(self, pixel_weight: float = 1.0, rec_loss_type: str = 'l1',
+                 spectral_weight: float = 0.0, spatial_weight: float = 0.0, freq_weight: float = 0.0,
+                 feature_weight: float = 0.0, msssim_weight: float = 0.0,
+                 spectral_start_step: int = 0, spatial_start_step: int = 0, freq_start_step: int = 0,
+                 feature_start_step: int = 0, msssim_start_step: int = 0, patch_factor: int = 2,
+                 ffl_alpha: float = 1.0, dofa_net: nn.Module = None, kl_weight: float = 0.0):
+        super().__init__()
+        for name, w in [('spectral', spectral_weight), ('spatial', spatial_weight),
+                        ('freq', freq_weight), ('feature', feature_weight)]:
+            if w > 0:
+                raise NotImplementedError(
+                    f'{name}_weight > 0: this loss branch is outside the MI355X hot path '
+                    '(weight 0 in configs/eo-vae.yaml)')
+        self.rec_loss_type = rec_loss_type
+        self.starts = {'spectral': spectral_start_step, 'spatial': spatial_start_step,
+                       'freq': freq_start_step, 'feature': feature_start_step,
+                       'msssim': msssim_start_step}
+        self.weights = {'pixel': pixel_weight, 'spectral': spectral_weight,
+                        'spatial': spatial_weight, 'freq': freq_weight, 'feature': feature_weight,
+                        'msssim': msssim_weight, 'kl': kl_weight}
+        self.char_loss = CharbonnierLoss()
+        self.msssim_loss = SSIMLoss()
+
+    def forward(self, inputs, wvs, reconstructions, global_step: int = 0, split: str = 'train',
+                posterior=None, **kwargs):
+        logs = {}
+        total = torch.zeros((), dtype=torch.float32, device=inputs.device)
+        if self.weights['pixel'] > 0:
+            if self.rec_loss_type == 'l1':
+                l_rec = ops.l1_loss(reconstructions, inputs)
+            elif self.rec_loss_type == 'char':
+                l_rec = self.char_loss(reconstructions, inputs)
+            else:
+                raise ValueError("rec_loss_type must be 'l1' or 'char'")
+            total = total + self.weights['pixel'] * l_rec
+            logs[f'{split}/loss_rec'] = l_rec.detach()
+        if self.weights['msssim'] > 0 and global_step >= self.starts['msssim']:
+            l_ms = self.msssim_loss(reconstructions, inputs)
+            total = total + self.weights['msssim'] * l_ms
+            logs[f'{split}/loss_msssim'] = l_ms.detach()
+        if self.weights['kl'] > 0 and posterior is not None:
+            l_kl = posterior.kl().mean()
+            total = total + self.weights['kl'] * l_kl
+            logs[f'{split}/loss_kl'] = l_kl.detach()
+        logs[f'{split}/loss_total'] = total.detach()
+        return total, logs

@@ -169,3 +169,212 @@ class GroupNormSiluFn(torch.autograd.Function):
 
 def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
     return GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu)
+
+
+# ------------------------------------------------------------------------------------------
+# attention core (softmax(Q^T K / sqrt(C)) V on [B, C, T] tensors)
+# ------------------------------------------------------------------------------------------
+
+
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        L.require_gpu(q, 'attention')
+        q, k, v = _c(q), _c(k), _c(v)
+        b, c, t = q.shape
+        p = torch.empty(b, t, t, dtype=torch.float32, device=q.device)
+        o = torch.empty_like(q)
+        L.check(L.load().eovae_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(p), L.ptr(o), b, c, t,
+                                             scale, L.stream()), 'eovae_attention_fwd')
+        ctx.save_for_backward(q, k, v, p)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p = ctx.saved_tensors
+        do = _c(do)
+        b, c, t = q.shape
+        dp = torch.empty_like(p)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        L.check(L.load().eovae_attention_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(p), L.ptr(do),
+                                             L.ptr(dp), L.ptr(dq), L.ptr(dk), L.ptr(dv), b, c, t,
+                                             ctx.scale, L.stream()), 'eovae_attention_bwd')
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, scale):
+    return AttentionFn.apply(q, k, v, scale)
+
+
+# ------------------------------------------------------------------------------------------
+# posterior, latent normalisation
+# ------------------------------------------------------------------------------------------
+
+
+class PosteriorSampleFn(torch.autograd.Function):
+    """z = mean + std * eps (eps=None -> mode)."""
+
+    @staticmethod
+    def forward(ctx, moments, eps):
+        L.require_gpu(moments, 'posterior')
+        moments = _c(moments)
+        b, c2, h, w = moments.shape
+        z = torch.empty(b, c2 // 2, h, w, dtype=torch.float32, device=moments.device)
+        eps = _c(eps) if eps is not None else None
+        L.check(L.load().eovae_posterior_fwd(L.ptr(moments), L.ptr(eps), L.ptr(z), None, b, c2 // 2,
+                                             h * w, L.stream()), 'eovae_posterior_fwd')
+        ctx.save_for_backward(moments, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        moments, eps = ctx.saved_tensors
+        b, c2, h, w = moments.shape
+        dm = torch.empty_like(moments)
+        L.check(L.load().eovae_posterior_bwd(L.ptr(moments), L.ptr(eps), L.ptr(_c(dz)), None,
+                                             L.ptr(dm), b, c2 // 2, h * w, L.stream()),
+                'eovae_posterior_bwd')
+        return dm, None
+
+
+class PosteriorKLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, moments):
+        L.require_gpu(moments, 'posterior.kl')
+        moments = _c(moments)
+        b, c2, h, w = moments.shape
+        kl = torch.empty(b, dtype=torch.float32, device=moments.device)
+        L.check(L.load().eovae_posterior_fwd(L.ptr(moments), None, None, L.ptr(kl), b, c2 // 2, h * w,
+                                             L.stream()), 'eovae_posterior_fwd')
+        ctx.save_for_backward(moments)
+        return kl
+
+    @staticmethod
+    def backward(ctx, dkl):
+        (moments,) = ctx.saved_tensors
+        b, c2, h, w = moments.shape
+        dm = torch.empty_like(moments)
+        L.check(L.load().eovae_posterior_bwd(L.ptr(moments), None, None, L.ptr(_c(dkl)), L.ptr(dm), b,
+                                             c2 // 2, h * w, L.stream()), 'eovae_posterior_bwd')
+        return dm
+
+
+class LatentNormFn(torch.autograd.Function):
+    """spatial z [B,Z,H,W] -> packed, batch-normalised zp [B,4Z,H/2,W/2] (running stats updated
+    in training mode, exactly as nn.BatchNorm2d(affine=False) does)."""
+
+    @staticmethod
+    def forward(ctx, z, run_mean, run_var, training, eps, momentum):
+        L.require_gpu(z, 'latent_norm')
+        z = _c(z)
+        b, zc, h, w = z.shape
+        zp = torch.empty(b, 4 * zc, h // 2, w // 2, dtype=torch.float32, device=z.device)
+        save = torch.empty(4 * zc * 2, dtype=torch.float32, device=z.device)
+        L.check(L.load().eovae_latent_bn_fwd(L.ptr(z), L.ptr(zp), L.ptr(run_mean), L.ptr(run_var),
+                                             L.ptr(save), b, zc, h, w, int(training), eps, momentum,
+                                             L.stream()), 'eovae_latent_bn_fwd')
+        ctx.save_for_backward(zp, save)
+        ctx.training, ctx.shape = training, (b, zc, h, w)
+        return zp
+
+    @staticmethod
+    def backward(ctx, dzp):
+        zp, save = ctx.saved_tensors
+        b, zc, h, w = ctx.shape
+        dz = torch.empty(b, zc, h, w, dtype=torch.float32, device=zp.device)
+        L.check(L.load().eovae_latent_bn_bwd(L.ptr(zp), L.ptr(_c(dzp)), L.ptr(save), L.ptr(dz), b, zc,
+                                             h, w, int(ctx.training), L.stream()),
+                'eovae_latent_bn_bwd')
+        return dz, None, None, None, None, None
+
+
+class LatentInvNormFn(torch.autograd.Function):
+    """packed normalised zp [B,4Z,h,w] -> spatial z [B,Z,2h,2w] = zp*sqrt(rv+eps)+rm."""
+
+    @staticmethod
+    def forward(ctx, zp, run_mean, run_var, eps):
+        L.require_gpu(zp, 'latent_inv_norm')
+        zp = _c(zp)
+        b, c4, h2, w2 = zp.shape
+        z = torch.empty(b, c4 // 4, 2 * h2, 2 * w2, dtype=torch.float32, device=zp.device)
+        L.check(L.load().eovae_latent_inv(L.ptr(zp), L.ptr(z), L.ptr(run_mean), L.ptr(run_var), b,
+                                          c4 // 4, 2 * h2, 2 * w2, eps, 0, L.stream()),
+                'eovae_latent_inv')
+        # the reference reads the running stats at forward time; keep a private copy for backward
+        ctx.save_for_backward(run_mean.clone(), run_var.clone())
+        ctx.eps, ctx.shape = eps, (b, c4 // 4, 2 * h2, 2 * w2)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        rm, rv = ctx.saved_tensors
+        b, zc, h, w = ctx.shape
+        dzp = torch.empty(b, 4 * zc, h // 2, w // 2, dtype=torch.float32, device=dz.device)
+        L.check(L.load().eovae_latent_inv(L.ptr(_c(dz)), L.ptr(dzp), L.ptr(rm), L.ptr(rv), b, zc, h, w,
+                                          ctx.eps, 1, L.stream()), 'eovae_latent_inv')
+        return dzp, None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------
+
+
+class PixelLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, kind, eps):
+        L.require_gpu(pred, 'pixel_loss')
+        pred, target = _c(pred), _c(target)
+        if pred.shape != target.shape:
+            raise L.EovaeError(f'pixel_loss: shapes differ {tuple(pred.shape)} vs {tuple(target.shape)}')
+        lib = L.load()
+        ws = workspace(lib.eovae_loss_workspace_bytes(), pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        L.check(lib.eovae_pixel_loss_fwd(L.ptr(pred), L.ptr(target), pred.numel(), kind, eps,
+                                         L.ptr(out), L.ptr(ws), L.stream()), 'eovae_pixel_loss_fwd')
+        ctx.save_for_backward(pred, target)
+        ctx.kind, ctx.eps = kind, eps
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        dpred = torch.empty_like(pred)
+        L.check(L.load().eovae_pixel_loss_bwd(L.ptr(pred), L.ptr(target), L.ptr(_c(gout)), L.ptr(dpred),
+                                              pred.numel(), ctx.kind, ctx.eps, L.stream()),
+                'eovae_pixel_loss_bwd')
+        return dpred, None, None, None
+
+
+def l1_loss(pred, target):
+    return PixelLossFn.apply(pred, target, 0, 0.0)
+
+
+def charbonnier_loss(pred, target, eps=1e-3):
+    return PixelLossFn.apply(pred, target, 1, eps)
+
+
+# ------------------------------------------------------------------------------------------
+# optimiser primitives on flat buffers
+# ------------------------------------------------------------------------------------------
+
+
+def grad_norm(flat_grad: torch.Tensor, max_norm: float, out: torch.Tensor) -> torch.Tensor:
+    """out[0] = ||g||, out[1] = clip coefficient (device side, no host sync)."""
+    lib = L.load()
+    ws = workspace(lib.eovae_gradnorm_workspace_bytes(), flat_grad.device)
+    L.check(lib.eovae_grad_norm(L.ptr(flat_grad), flat_grad.numel(), float(max_norm or 0.0),
+                                L.ptr(out), L.ptr(ws), L.stream()), 'eovae_grad_norm')
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, clip=None, grad_scale=1.0):
+    L.check(L.load().eovae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1,
+                                     beta2, eps, step, L.ptr(clip), grad_scale, L.stream()),
+            'eovae_adam_step')
+
+
+def scale_inplace(g, clip=None, s=1.0):
+    L.check(L.load().eovae_scale_inplace(L.ptr(g), g.numel(), L.ptr(clip), s, L.stream()),
+            'eovae_scale_inplace')

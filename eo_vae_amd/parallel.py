@@ -1,0 +1,105 @@
+"""Data parallelism: one process per GPU, gradient all-reduce over RCCL/xGMI.
+
+The reference only ever reaches this through Lightning's `strategy: ddp` (configs/eo-vae.yaml:80,
+SURVEY.md 2b C1-C6).  Here the engine is explicit and small:
+  * parameters and gradients live in ONE flat buffer each (optim.FlatParams);
+  * the gradient buffer is cut into buckets from the END (decoder gradients are produced
+    first); a post-accumulate hook counts a bucket's parameters down and launches its
+    all-reduce (async, RCCL stream) the moment the last one is ready, so communication
+    overlaps the rest of the backward pass;
+  * averaging uses ReduceOp.AVG on RCCL (SUM + scale on gloo for the CPU tests);
+  * gradient clipping runs after finish() on the averaged gradient, so every rank computes
+    the same norm with no further collective (same order as manual_backward -> clip_grad_norm_,
+    new_autoencoder.py:648-652)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'  # 'nccl' IS RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class BucketedGradReducer:
+    def __init__(self, flat, group=None, bucket_mb: float = 48.0):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.use_avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        cap = int(bucket_mb * (1 << 20) / flat.grad.element_size())
+        # buckets = contiguous [start, end) ranges of the flat gradient, built back to front
+        self.buckets, self.bucket_of = [], {}
+        end, members = flat.total, []
+        for i in reversed(range(len(flat.params))):
+            members.append(i)
+            start = flat.offsets[i]
+            if end - start >= cap or i == 0:
+                self.buckets.append((start, end, list(members)))
+                end, members = start, []
+        for b, (_, _, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                self.bucket_of[id(flat.params[i])] = b
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+        self.handles = []
+        if self.world > 1:
+            for p in flat.params:
+                if p.requires_grad:
+                    self.handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ---- start-of-training synchronisation (DDP constructor broadcast, C1) ----
+    def broadcast_parameters(self, buffers=()):
+        if self.world == 1:
+            return
+        dist.broadcast(self.flat.data, src=0, group=self.group)
+        for b in buffers:
+            dist.broadcast(b, src=0, group=self.group)
+
+    def _on_grad(self, p):
+        b = self.bucket_of[id(p)]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        start, end, _ = self.buckets[b]
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        self.works.append(dist.all_reduce(self.flat.grad[start:end], op=op, group=self.group,
+                                          async_op=True))
+        self.launched[b] = True
+
+    def finish(self):
+        """Call after backward: launches buckets whose parameters received no gradient, waits
+        for every collective, leaves the AVERAGED gradient in flat.grad."""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        if not self.use_avg:
+            self.flat.grad.mul_(1.0 / self.world)
+        self.works = []
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.launched = [False] * len(self.buckets)
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []

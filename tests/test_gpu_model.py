@@ -1,0 +1,105 @@
+"""GPU: the HIP product path (eo_vae_amd) against the CPU oracle and the golden fixtures.
+Tolerances from BASELINE.json north_star: reconstructions/latents 1e-3 relative, loss scalars 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REL_OUT = 1e-3      # reconstructions / latents
+REL_LOSS = 1e-4     # loss scalars
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def build_pair(cfg_kwargs, seed):
+    from oracle import eo_vae_cpu as O
+    from eo_vae_amd.autoencoder import EOFluxVAE
+    from eo_vae_amd.model import Decoder, Encoder
+    cfg = O.model_cfg(**cfg_kwargs)
+    oracle = O.build_vae(cfg)
+    O.det_fill(oracle, seed=seed)
+    prod = EOFluxVAE(Encoder(**cfg['encoder']), Decoder(**cfg['decoder']), torch.nn.Identity(),
+                     freeze_body=False)
+    assert list(prod.state_dict().keys()) == list(oracle.state_dict().keys())
+    prod.load_state_dict(oracle.state_dict())
+    return oracle, prod.cuda()
+
+
+def test_tiny_eval_api_against_golden_and_oracle(golden):
+    from oracle import eo_vae_cpu as O
+    g = golden('tiny_eval')
+    oracle, prod = build_pair(O.TINY, 21)
+    oracle.eval(), prod.eval()
+    for mod in ['S2RGB', 'S1RTC', 'S2L2A']:
+        wvs = torch.tensor(O.WAVELENGTHS[mod])
+        x = T(g[f'{mod}.x'])
+        xg, wg = x.cuda(), wvs.cuda()
+        assert rel(prod.reconstruct(xg, wg), g[f'{mod}.recon']) < REL_OUT
+        assert rel(prod.encode_to_latent(xg, wg), g[f'{mod}.latent']) < REL_OUT
+        assert rel(prod.encode_spatial_normalized(xg, wg), g[f'{mod}.spatial']) < REL_OUT
+        assert rel(prod.encode(xg, wg).parameters, g[f'{mod}.moments']) < REL_OUT
+        assert rel(prod.decode_spatial_normalized(T(g[f'{mod}.spatial']).cuda(), wg), g[f'{mod}.dec']) < REL_OUT
+        assert rel(prod.reconstruct(xg, wg), oracle.reconstruct(x, wvs)) < REL_OUT
+
+
+def test_tiny_train_forward_backward(golden):
+    """One train-mode forward/backward: recon, KL, every parameter gradient vs the oracle.
+    The gradient comparison uses the smooth Charbonnier loss (the reference config's
+    rec_loss_type): L1's sign() gradient flips on the handful of pixels where |recon - x| is
+    below the fp32 forward round-off (~1e-5), which alone moves parameter gradients by ~2e-3."""
+    from oracle import eo_vae_cpu as O
+    g = golden('tiny_train')
+    oracle, prod = build_pair(O.TINY, 21)
+    oracle.train(), prod.train()
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    x, eps = T(g['x0']), T(g['eps0'])
+    rec_o, post_o = oracle(x, wvs, noise=eps)
+    loss_o = O.charbonnier(rec_o, x) + 1e-6 * post_o.kl().mean()
+    l1_o = torch.nn.functional.l1_loss(rec_o, x)
+    loss_o.backward()
+    from eo_vae_amd import ops
+    rec_p, post_p = prod(x.cuda(), wvs.cuda(), noise=eps.cuda())
+    loss_p = ops.charbonnier_loss(rec_p, x.cuda()) + 1e-6 * post_p.kl().mean()
+    l1_p = ops.l1_loss(rec_p, x.cuda())
+    loss_p.backward()
+    torch.cuda.synchronize()
+    assert rel(rec_p, g['recon0']) < REL_OUT
+    assert rel(post_p.kl(), g['kl0']) < REL_OUT
+    assert abs(loss_p.item() - loss_o.item()) <= REL_LOSS * abs(loss_o.item())
+    assert abs(l1_p.item() - l1_o.item()) <= REL_LOSS * abs(l1_o.item())
+    po, pp = dict(oracle.named_parameters()), dict(prod.named_parameters())
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in po.values() if p.grad is not None)))
+    worst = 0.0
+    for k, p in po.items():
+        if p.grad is None:
+            continue
+        err = (pp[k].grad.double().cpu() - p.grad.double()).norm().item()
+        worst = max(worst, err / max(p.grad.double().norm().item(), 1e-3 * tot))
+    assert worst < 5e-4, worst
+    sd_o, sd_p = oracle.state_dict(), prod.state_dict()
+    assert rel(sd_p['bn.running_mean'], sd_o['bn.running_mean']) < 1e-4
+    assert rel(sd_p['bn.running_var'], sd_o['bn.running_var']) < 1e-4
+    assert int(sd_p['bn.num_batches_tracked']) == int(sd_o['bn.num_batches_tracked'])
+
+
+def test_full_size_cfg1_reconstruct(golden):
+    """BASELINE config 1 on the GPU: S2RGB 3-ch 256x256, batch 2, reconstruct()."""
+    from oracle import eo_vae_cpu as O
+    g = golden('full_cfg1')
+    _, prod = build_pair({}, 31)
+    prod.eval()
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    rec = prod.reconstruct(x.cuda(), wvs.cuda())
+    spat = prod.encode_spatial_normalized(x.cuda(), wvs.cuda())
+    torch.cuda.synchronize()
+    assert rel(rec[:, :, ::8, ::8], g['recon_sub']) < REL_OUT
+    assert rel(spat[:, :, ::2, ::2], g['spatial_sub']) < REL_OUT
