@@ -55,6 +55,9 @@ class _MiniLightningModule(torch.nn.Module):
 
     def manual_backward(self, loss, *args, **kwargs):
         loss.backward(*args, **kwargs)
+        reducer = getattr(self._trainer, 'reducer', None)
+        if reducer is not None:  # wait for the bucketed RCCL all-reduces launched during backward
+            reducer.finish()
 
     def log_dict(self, metrics, **kwargs):
         self.logged.update(metrics)

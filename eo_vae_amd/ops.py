@@ -59,13 +59,43 @@ def _out_hw(h, w, mode):
     return 2 * h, 2 * w
 
 
+class KernelTimer:
+    """Opt-in HIP-event bracket around every launch of one kernel family on the launch stream
+    (bench.py: roofline.achieved = algorithmic flops / measured kernel time)."""
+
+    def __init__(self):
+        self.records = []  # (start_event, end_event, algorithmic_flops)
+
+    def bracket(self, flops):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((a, b, flops))
+        return a, b
+
+    def totals(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        return ms, sum(f for _, _, f in self.records), len(self.records)
+
+
+CONV3X3_TIMER: KernelTimer | None = None  # set by bench.py during the timed region
+
+
 def conv_raw(x, wp, kp, mp, bias, residual, cout, ks, mode, out_scale=1.0):
     n, cin, h, w = x.shape
     ho, wo = _out_hw(h, w, mode)
     y = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
+    timed = CONV3X3_TIMER is not None and ks == 3 and mode != MODE_DOWN
+    if timed:
+        # algorithmic flops of the layer this launch implements (MODE_ZINS = adjoint of the
+        # stride-2 layer: its algorithmic work is the stride-2 layer's, a quarter of the tile work)
+        pix = (ho * wo) // 4 if mode == MODE_ZINS else ho * wo
+        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout * cin * 9)
+        ev0.record()
     L.check(L.load().eovae_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
                                       n, cin, h, w, cout, ho, wo, ks, mode, kp, mp, out_scale,
                                       L.stream()), 'eovae_conv2d_fwd')
+    if timed:
+        ev1.record()
     return y
 
 

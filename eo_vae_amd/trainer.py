@@ -1,0 +1,164 @@
+"""Minimal fit loop standing in for `lightning.Trainer` (not installed on the MI355X image).
+
+Covers what the reference's train.py needs from it (train.py:139-174): manual-optimisation
+training_step calls, per-step LR scheduling inside the module, periodic validation, CSV metrics
+(`train|val/loss_*`, `train/lr`), top-1 + last checkpoints on `val/loss_rec`, and data parallelism
+(one process per GPU; gradient all-reduce handled by parallel.BucketedGradReducer)."""
+from __future__ import annotations
+
+import csv
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .parallel import BucketedGradReducer, init_distributed
+
+
+def _scalar(v):
+    if isinstance(v, torch.Tensor):
+        return float(v.detach().float().cpu())
+    return float(v)
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = 1, max_steps: int = -1, limit_train_batches=None,
+                 limit_val_batches=None, log_every_n_steps: int = 50, default_root_dir: str | None = None,
+                 callbacks=None, logger=None, accelerator: str = 'gpu', devices=None,
+                 precision='32-true', strategy: str | None = None, bucket_mb: float = 48.0,
+                 enable_checkpointing: bool = True, **ignored):
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
+        self.log_every_n_steps = max(1, int(log_every_n_steps))
+        self.default_root_dir = default_root_dir
+        self.enable_checkpointing = enable_checkpointing and default_root_dir is not None
+        self.bucket_mb = bucket_mb
+        self.precision = precision  # parity path is fp32 storage; AMP ('16-mixed') is not emulated
+        self.rank, self.world, self.local_rank = 0, 1, 0
+        self.reducer = None
+        self.current_epoch = 0
+        self._pending, self._csv_rows = {}, []
+        self.best_val = float('inf')
+        self.history = []
+
+    # ------------------------------------------------------------------ logging
+    def log_metrics(self, metrics, **kwargs):
+        self._pending.update(metrics)
+
+    def _flush(self, step, prefix_filter=None):
+        if not self._pending:
+            return {}
+        row = {'step': step, 'epoch': self.current_epoch}
+        row.update({k: _scalar(v) for k, v in self._pending.items()})
+        self._pending = {}
+        self.history.append(row)
+        if self.rank == 0 and self.default_root_dir:
+            self._csv_rows.append(row)
+            keys = sorted({k for r in self._csv_rows for k in r})
+            with open(os.path.join(self.default_root_dir, 'metrics.csv'), 'w', newline='') as f:
+                w = csv.DictWriter(f, fieldnames=keys)
+                w.writeheader()
+                w.writerows(self._csv_rows)
+        return row
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
+        self.rank, self.world, self.local_rank = init_distributed()
+        if not torch.cuda.is_available():
+            from .lib import EovaeError
+            raise EovaeError('Trainer.fit: no AMD GPU visible; the HIP hot path has no CPU fallback')
+        device = torch.device('cuda', self.local_rank)
+        torch.cuda.set_device(device)
+        model.to(device)
+        if self.default_root_dir and self.rank == 0:
+            os.makedirs(self.default_root_dir, exist_ok=True)
+        if datamodule is not None:
+            datamodule.setup('fit', device=device, rank=self.rank)
+            train_loader, val_loader = datamodule.train_dataloader(), datamodule.val_dataloader()
+        else:
+            train_loader, val_loader = train_dataloaders, val_dataloaders
+
+        conf = model.configure_optimizers()
+        if isinstance(conf, tuple):
+            optimizers, sched_cfgs = conf
+        else:
+            optimizers, sched_cfgs = (conf if isinstance(conf, (list, tuple)) else [conf]), []
+        schedulers = [s['scheduler'] if isinstance(s, dict) else s for s in sched_cfgs]
+        model.attach(self, optimizers, schedulers)
+        flat = getattr(optimizers[0], 'flat', None)
+        buffers = [b for b in model.buffers() if b.is_floating_point()]
+        if self.world > 1:
+            if flat is None:
+                raise RuntimeError('data parallelism needs the flat-buffer optimiser (FusedAdam)')
+            self.reducer = BucketedGradReducer(flat, bucket_mb=self.bucket_mb)
+            self.reducer.broadcast_parameters(buffers)
+
+        done = False
+        t0 = time.time()
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            model.train()
+            for i, batch in enumerate(train_loader):
+                if self.limit_train_batches is not None and i >= self.limit_train_batches:
+                    break
+                if self.world > 1:  # DDP broadcast_buffers=True semantics
+                    for b in buffers:
+                        dist.broadcast(b, src=0)
+                model.training_step(batch, i)
+                model._global_step += 1
+                if model._global_step % self.log_every_n_steps == 0:
+                    row = self._flush(model._global_step)
+                    if self.rank == 0 and row:
+                        shown = ' '.join(f'{k}={v:.5g}' for k, v in row.items() if k.startswith('train/'))
+                        print(f'[epoch {epoch} step {model._global_step} {time.time() - t0:.0f}s] {shown}',
+                              flush=True)
+                else:
+                    self._pending = {}
+                if self.max_steps > 0 and model._global_step >= self.max_steps:
+                    done = True
+                    break
+            self.validate(model, val_loader)
+            if done:
+                break
+        if self.reducer is not None:
+            self.reducer.remove()
+        return self
+
+    @torch.no_grad()
+    def validate(self, model, val_loader):
+        if val_loader is None:
+            return {}
+        model.eval()
+        sums, n = {}, 0
+        for i, batch in enumerate(val_loader):
+            if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                break
+            model.validation_step(batch, i)
+            for k, v in self._pending.items():
+                sums[k] = sums.get(k, 0.0) + _scalar(v)
+            self._pending = {}
+            n += 1
+        model.train()
+        if n == 0:
+            return {}
+        means = {k: v / n for k, v in sums.items()}
+        if self.world > 1:  # ModelCheckpoint's decision must agree on every rank (C4)
+            t = torch.tensor([means.get('val/loss_rec', 0.0)], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            means['val/loss_rec'] = float(t) / self.world
+        self._pending = dict(means)
+        self._flush(model._global_step)
+        if self.rank == 0:
+            print('[val] ' + ' '.join(f'{k}={v:.5g}' for k, v in means.items()), flush=True)
+            if self.enable_checkpointing:
+                self._checkpoint(model, means.get('val/loss_rec'))
+        return means
+
+    def _checkpoint(self, model, val):
+        payload = {'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                   'global_step': model._global_step, 'epoch': self.current_epoch}
+        torch.save(payload, os.path.join(self.default_root_dir, 'last.ckpt'))
+        if val is not None and val < self.best_val:
+            self.best_val = val
+            torch.save(payload, os.path.join(self.default_root_dir, 'best.ckpt'))
