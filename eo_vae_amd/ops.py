@@ -408,3 +408,49 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, clip=None, grad_scale=1.0
 def scale_inplace(g, clip=None, s=1.0):
     L.check(L.load().eovae_scale_inplace(L.ptr(g), g.numel(), L.ptr(clip), s, L.stream()),
             'eovae_scale_inplace')
+
+
+# ------------------------------------------------------------------------------------------
+# MS-SSIM (5-scale Gaussian pyramid) and encode_latents running statistics
+# ------------------------------------------------------------------------------------------
+
+
+class MSSSIMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, data_range, betas):
+        L.require_gpu(pred, 'msssim')
+        pred, target = _c(pred), _c(target)
+        b, c, h, w = pred.shape
+        lib = L.load()
+        nbytes = lib.eovae_msssim_workspace_bytes(b, c, h, w, len(betas))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)  # kept until backward
+        bt = torch.tensor(betas, dtype=torch.float32, device=pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        L.check(lib.eovae_msssim_fwd(L.ptr(pred), L.ptr(target), L.ptr(out), b, c, h, w, len(betas),
+                                     L.ptr(bt), data_range, L.ptr(ws), L.stream()), 'eovae_msssim_fwd')
+        ctx.save_for_backward(pred, target, ws, bt)
+        ctx.data_range = data_range
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, ws, bt = ctx.saved_tensors
+        b, c, h, w = pred.shape
+        dpred = torch.empty_like(pred)
+        L.check(L.load().eovae_msssim_bwd(L.ptr(pred), L.ptr(target), L.ptr(_c(gout)), L.ptr(dpred), b, c,
+                                          h, w, bt.numel(), L.ptr(bt), ctx.data_range, L.ptr(ws),
+                                          L.stream()), 'eovae_msssim_bwd')
+        return dpred, None, None, None
+
+
+def msssim(pred, target, data_range=6.0, betas=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333)):
+    return MSSSIMFn.apply(pred, target, float(data_range), tuple(betas))
+
+
+def running_stats_update(z: torch.Tensor, state: torch.Tensor) -> None:
+    """state [5, C] = (mean, var, min, max, count); z [B, C, H, W]."""
+    L.require_gpu(z, 'running_stats')
+    z = _c(z)
+    b, c = z.shape[:2]
+    L.check(L.load().eovae_running_stats_update(L.ptr(z), L.ptr(state), b, c, z[0, 0].numel(), L.stream()),
+            'eovae_running_stats_update')

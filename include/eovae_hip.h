@@ -1,0 +1,164 @@
+/* eovae_hip.h -- C ABI of libeovae_hip.so: the MI355X (gfx950) kernels behind EO-VAE's
+ * data-parallel hot path.
+ *
+ * The reference (nilsleh/eo-vae) is pure Python: its "FFI" for this path is the set of ATen
+ * operator calls made by eo_vae/models/{model.py, new_autoencoder.py} and
+ * eo_vae/models/modules/{layers.py, dynamic_conv.py, distributions.py, consistency_loss.py}.
+ * Each entry point below names the reference call site it replaces (file:line relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = error; eovae_last_error() gives the thread-local text
+ *   - all tensors: contiguous NCHW fp32 device memory, allocated and owned by the CALLER
+ *     (PyTorch-ROCm); the library never allocates, frees or retains a pointer past the call
+ *   - `stream` is a hipStream_t (0 = default); every call only ENQUEUES work on it, never
+ *     synchronises, and is safe to capture into a hipGraph
+ *   - re-entrant; no global mutable state except the thread-local error string
+ *   - scratch needed by a call is passed in (`ws`); sizes come from *_workspace_bytes()
+ */
+#ifndef EOVAE_HIP_H
+#define EOVAE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* eovae_last_error(void);
+int eovae_abi_version(void);
+const char* eovae_target_arch(void); /* "gfx950" */
+
+/* ----------------------------------------------------------------------------------------
+ * Convolution = implicit GEMM on the matrix cores (csrc/conv_f32.hip)
+ *   mode 0 NORMAL : stride 1, pad (KS-1)/2   nn.Conv2d 3x3/1x1      layers.py:64-66,81-87,123-126
+ *                                            model.py:162,165,236,260; F.conv2d dynamic_conv.py:527-533,699-705
+ *   mode 1 DOWN   : F.pad(0,1,0,1) + 3x3 stride 2                    layers.py:33-37
+ *   mode 2 UP     : F.interpolate(nearest x2) + 3x3 stride 1 pad 1   layers.py:47-50
+ *   mode 3 ZINS   : adjoint of DOWN w.r.t. its input (zero-insert x2, window offset -2)
+ * Weights are consumed PACKED: wp[tap][KP][MP] (zero padded), produced by eovae_conv_pack_weights
+ * from the PyTorch layout w[Cout][Cin][KS][KS]:
+ *   flip = 0  forward operand        (k = Cin, m = Cout)
+ *   flip = 1  data-gradient operand  (k = Cout, m = Cin, taps rotated 180 degrees)
+ * -------------------------------------------------------------------------------------- */
+int eovae_conv_packed_dims(int Cout, int Cin, int KS, int mode, int flip, int* KP, int* MP);
+int eovae_conv_pack_weights(const float* w, float* wp, int Cout, int Cin, int KS, int mode,
+                            int flip, float scale, void* stream);
+/* y[N][Cout][Hout][Wout] = conv(x[N][Cin][Hin][Win], wp) * out_scale + bias[Cout] + residual;
+ * bias / residual may be NULL.  For a data-gradient call pass (Cin, Cout) swapped together with
+ * the flip-packed weights: dx = conv2d_fwd(dy, wp_flip). */
+int eovae_conv2d_fwd(const float* x, const float* wp, const float* bias, const float* residual,
+                     float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                     int KS, int mode, int KP, int MP, float out_scale, void* stream);
+/* dwp[tap][Cout][Cin] += sum_{n,pix} dy * x (mode 0/1/2 of the FORWARD layer); caller zero-fills */
+int eovae_conv2d_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
+                       int Win, int Cout, int Hout, int Wout, int KS, int mode, void* stream);
+/* dwp[tap][Cout][Cin] -> dw[Cout][Cin][KS][KS] */
+int eovae_conv_unpack_wgrad(const float* dwp, float* dw, int Cout, int Cin, int KS, void* stream);
+/* db[C] = sum_{n,hw} dy[N][C][HW] */
+int eovae_bias_grad(const float* dy, float* db, int N, int C, int HW, void* stream);
+/* adjoint of nearest x2: dx[N][C][H][W] = 2x2 block sums of du[N][C][2H][2W] */
+int eovae_upsample2x_bwd(const float* du, float* dx, int N, int C, int H, int W, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * GroupNorm(G groups, eps, affine) [+ x*sigmoid(x)]  (csrc/groupnorm.hip)
+ *   nn.GroupNorm(32, C, eps=1e-6) + swish: layers.py:61-63,78-80,91-92,106-108;
+ *   model.py:159-161,193-194,295-297,349-350.  silu = 0 for AttnBlock.norm (layers.py:119-121,129)
+ * stats[N*G][2] = (mean, rstd) is produced by the forward and consumed by the backward.
+ * -------------------------------------------------------------------------------------- */
+size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G);
+int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                      int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream);
+/* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C] */
+int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
+                      const float* stats, const float* dx_add, float* dx, float* dgamma,
+                      float* dbeta, int N, int C, int HW, int G, int silu, void* ws, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Bottleneck attention (csrc/attention.hip): F.scaled_dot_product_attention, one head, d = C
+ *   layers.py:133-139.  q,k,v,o: [B][C][T] (NCHW conv outputs, token index contiguous).
+ * -------------------------------------------------------------------------------------- */
+/* strided-batched fp32 GEMM on MFMA: C(m,n) = alpha * sum_k A(m,k) B(k,n), element strides */
+int eovae_gemm_f32(const float* A, const float* B, float* C, int batch, int M, int N, int K,
+                   long long sam, long long sak, long long sbk, long long sbn, long long scm,
+                   long long scn, long long batA, long long batB, long long batC, float alpha,
+                   void* stream);
+int eovae_softmax_rows(float* s, long long rows, int n, void* stream);
+int eovae_softmax_bwd_rows(const float* p, float* dp, long long rows, int n, void* stream);
+/* p[B][T][T] receives softmax(scale * q^T k) and must be kept for the backward */
+int eovae_attention_fwd(const float* q, const float* k, const float* v, float* p, float* o, int B,
+                        int C, int T, float scale, void* stream);
+/* dp[B][T][T] is scratch */
+int eovae_attention_bwd(const float* q, const float* k, const float* v, const float* p,
+                        const float* d_o, float* dp, float* dq, float* dk, float* dv, int B, int C,
+                        int T, float scale, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Latent glue (csrc/latent.hip)
+ *   posterior: DiagonalGaussianDistribution            distributions.py:28-32,44-46,64-67
+ *   latent_bn: rearrange 2x2 unshuffle + nn.BatchNorm2d(4Z, affine=False)
+ *                                                       new_autoencoder.py:466-469,533-536
+ *   latent_inv: inverse BN (running stats, eps 1e-4) + 2x2 shuffle   new_autoencoder.py:423-428,538-543
+ * -------------------------------------------------------------------------------------- */
+/* moments[B][2Z][HW]; eps NULL => mode; z and/or kl[B] may be NULL */
+int eovae_posterior_fwd(const float* moments, const float* eps, float* z, float* kl, int B, int Z,
+                        int HW, void* stream);
+int eovae_posterior_bwd(const float* moments, const float* eps, const float* dz, const float* dkl,
+                        float* dmoments, int B, int Z, int HW, void* stream);
+/* z[B][Z][H][W] -> zp[B][4Z][H/2][W/2]; training: batch stats + running-stat update
+ * (momentum, unbiased variance); save[4Z][2] = (mean, invstd) for the backward */
+int eovae_latent_bn_fwd(const float* z, float* zp, float* run_mean, float* run_var, float* save,
+                        int B, int Z, int H, int W, int training, float eps, float momentum,
+                        void* stream);
+int eovae_latent_bn_bwd(const float* zp, const float* dzp, const float* save, float* dz, int B,
+                        int Z, int H, int W, int training, void* stream);
+/* backward = 0: zp -> z = zp*sqrt(run_var+eps)+run_mean (spatial); backward = 1: dz -> dzp */
+int eovae_latent_inv(const float* src, float* dst, const float* run_mean, const float* run_var,
+                     int B, int Z, int H, int W, float eps, int backward, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Losses (csrc/loss.hip, csrc/msssim.hip): EOConsistencyLoss   consistency_loss.py:399-483
+ *   kind 0 = F.l1_loss (:418), kind 1 = CharbonnierLoss eps (:12-21)
+ *   MS-SSIM: torchmetrics MultiScaleStructuralSimilarityIndexMeasure(data_range=6,
+ *            gaussian sigma 1.5 => 11 taps, 5 betas, normalize='relu')   consistency_loss.py:24-37
+ * -------------------------------------------------------------------------------------- */
+size_t eovae_loss_workspace_bytes(void);
+int eovae_pixel_loss_fwd(const float* pred, const float* target, size_t n, int kind, float eps,
+                         float* out, void* ws, void* stream);
+/* gout: device scalar holding d(total)/d(loss) */
+int eovae_pixel_loss_bwd(const float* pred, const float* target, const float* gout, float* dpred,
+                         size_t n, int kind, float eps, void* stream);
+/* bytes for the image pyramid + per-scale statistics kept between forward and backward */
+size_t eovae_msssim_workspace_bytes(int B, int C, int H, int W, int scales);
+/* out[0] = mean_b prod_s v_{s,b}^{beta_s}; ws keeps pyramid + per-image factors */
+int eovae_msssim_fwd(const float* pred, const float* target, float* out, int B, int C, int H, int W,
+                     int scales, const float* betas, float data_range, void* ws, void* stream);
+/* dpred = gout[0] * d(msssim)/d(pred), using the state the forward left in ws */
+int eovae_msssim_bwd(const float* pred, const float* target, const float* gout, float* dpred, int B,
+                     int C, int H, int W, int scales, const float* betas, float data_range, void* ws,
+                     void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Optimiser step over ONE flat buffer (csrc/optim.hip)
+ *   torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step   new_autoencoder.py:649-653
+ * -------------------------------------------------------------------------------------- */
+size_t eovae_gradnorm_workspace_bytes(void);
+/* norm_out[0] = ||g||_2, norm_out[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0) */
+int eovae_grad_norm(const float* g, size_t n, float max_norm, float* norm_out, void* ws,
+                    void* stream);
+/* step = Adam step count after increment; clip (may be NULL) = norm_out of eovae_grad_norm */
+int eovae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, int step, const float* clip, float grad_scale,
+                    void* stream);
+int eovae_scale_inplace(float* g, size_t n, const float* clip, float s, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * encode_latents.py running statistics (csrc/stats.hip): RunningStatsButFast.update
+ *   encode_latents.py:65-94.  state[5][C] = mean, var, min, max, (count replicated)
+ * -------------------------------------------------------------------------------------- */
+int eovae_running_stats_update(const float* z, float* state, int B, int C, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOVAE_HIP_H */

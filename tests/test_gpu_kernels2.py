@@ -1,0 +1,287 @@
+"""GPU: attention, latent glue, losses, optimiser and statistics kernels against fp32 PyTorch-CPU
+statements / the oracle / golden fixtures."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def hashed(shape, salt, scale=1.0):
+    from oracle.eo_vae_cpu import _hash_uniform
+    n = int(np.prod(shape))
+    return (_hash_uniform(n, salt).reshape(shape) * (scale * 12 ** 0.5)).float()
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize('b,c,t', [(2, 64, 64), (1, 512, 1024), (2, 96, 200)])
+def test_attention_core(b, c, t):
+    from eo_vae_amd import ops
+    q, k, v = (hashed((b, c, t), s, 1.0) for s in (1, 2, 3))
+    go = hashed((b, c, t), 4, 1.0)
+    qr, kr, vr = (x.clone().requires_grad_(True) for x in (q, k, v))
+    s = torch.einsum('bci,bcj->bij', qr, kr) * c ** -0.5
+    o = torch.einsum('bij,bcj->bci', torch.softmax(s, -1), vr)
+    o.backward(go)
+    qg, kg, vg = (x.cuda().requires_grad_(True) for x in (q, k, v))
+    og = ops.attention(qg, kg, vg, c ** -0.5)
+    og.backward(go.cuda())
+    assert rel(og, o) < 1e-5
+    assert rel(qg.grad, qr.grad) < 5e-5 and rel(kg.grad, kr.grad) < 5e-5 and rel(vg.grad, vr.grad) < 5e-5
+
+
+def test_attention_block_against_golden(golden):
+    from oracle import eo_vae_cpu as O
+    from eo_vae_amd.layers import AttnBlock
+    for name in ['op_attn_8', 'op_attn_16']:
+        g = golden(name)
+        ref = O.AttnBlock(64)
+        O.det_fill(ref, seed=12, gain=2.0)
+        blk = AttnBlock(64)
+        blk.load_state_dict(ref.state_dict())
+        blk.cuda()
+        x = T(g['x']).cuda().requires_grad_(True)
+        y = blk(x)
+        y.backward(T(g['gy']).cuda())
+        assert rel(y, g['y']) < 1e-5
+        assert rel(x.grad, g['gx']) < 1e-4
+        scale = max(np.abs(g['g.' + k]).max() for k, _ in blk.named_parameters())
+        for k, p in blk.named_parameters():   # k.bias gradient is analytically 0 -> absolute scale
+            assert (p.grad.cpu() - T(g['g.' + k])).abs().max().item() < 1e-4 * scale, k
+
+
+def test_resnet_down_up_against_golden(golden):
+    from oracle import eo_vae_cpu as O
+    from eo_vae_amd import layers as PL
+    cases = [('op_res_same', O.ResnetBlock(32, 32), PL.ResnetBlock(32, 32), 11),
+             ('op_res_proj', O.ResnetBlock(32, 64), PL.ResnetBlock(32, 64), 11),
+             ('op_down', O.Downsample(32), PL.Downsample(32), 13),
+             ('op_up', O.Upsample(32), PL.Upsample(32), 13)]
+    for name, ref, blk, seed in cases:
+        g = golden(name)
+        O.det_fill(ref, seed=seed)
+        blk.load_state_dict(ref.state_dict())
+        blk.cuda()
+        x = T(g['x']).cuda().requires_grad_(True)
+        y = blk(x)
+        y.backward(T(g['gy']).cuda())
+        assert rel(y, g['y']) < 1e-5, name
+        assert rel(x.grad, g['gx']) < 1e-4, name
+        scale = max(np.abs(g['g.' + k]).max() for k, _ in blk.named_parameters())
+        for k, p in blk.named_parameters():   # a conv bias feeding a GroupNorm has zero true gradient
+            assert (p.grad.cpu() - T(g['g.' + k])).abs().max().item() < 1e-4 * scale, (name, k)
+
+
+def test_dynamic_convs_against_golden(golden):
+    from oracle import eo_vae_cpu as O
+    from eo_vae_amd.dynamic_conv import DynamicConv, DynamicConv_decoder
+    g = golden('op_dynconv')
+    ref_in = O.DynamicConv(wv_planes=256, embed_dim=128, num_layers=4)
+    ref_out = O.DynamicConv_decoder(wv_planes=256, embed_dim=128, num_layers=4)
+    O.det_fill(ref_in, seed=14)
+    O.det_fill(ref_out, seed=15)
+    din = DynamicConv(wv_planes=256, inter_dim=128, embed_dim=128, num_layers=4)
+    dout = DynamicConv_decoder(wv_planes=256, inter_dim=128, embed_dim=128, num_layers=4)
+    din.load_state_dict(ref_in.state_dict())
+    dout.load_state_dict(ref_out.state_dict())
+    din.cuda().eval(), dout.cuda().eval()
+    for mod, wl in O.WAVELENGTHS.items():
+        wvs = torch.tensor(wl).cuda()
+        with torch.no_grad():
+            assert rel(din(T(g[f'{mod}.x']).cuda(), wvs), g[f'{mod}.y_in']) < 1e-4
+            assert rel(dout(T(g[f'{mod}.h']).cuda(), wvs), g[f'{mod}.y_out']) < 1e-4
+            w, b = din.get_distillation_weight(wvs)
+            assert rel(w, g[f'{mod}.w_in']) < 1e-4 and rel(b, g[f'{mod}.b_in']) < 1e-4
+
+
+def test_posterior_against_golden(golden):
+    from eo_vae_amd.distributions import DiagonalGaussianDistribution
+    g = golden('op_posterior')
+    mom = T(g['moments']).cuda().requires_grad_(True)
+    p = DiagonalGaussianDistribution(mom)
+    z = p.sample(T(g['eps']).cuda())
+    kl = p.kl()
+    assert rel(z, g['sample']) < 1e-6 and rel(kl, g['kl']) < 1e-6
+    assert torch.equal(p.mode().cpu(), T(g['mode']))
+    # gradients vs torch CPU (covers the clamp mask at +-30/20)
+    mr = T(g['moments']).clone().requires_grad_(True)
+    mean, lv = torch.chunk(mr, 2, 1)
+    lvc = torch.clamp(lv, -30.0, 20.0)
+    zr = mean + torch.exp(0.5 * lvc) * T(g['eps'])
+    klr = 0.5 * torch.sum(mean ** 2 + torch.exp(lvc) - 1.0 - lvc, dim=[1, 2, 3])
+    gz = hashed(tuple(zr.shape), 9, 1.0)
+    (zr * gz).sum().backward(retain_graph=True)
+    (0.3 * klr.sum()).backward()
+    ((z * gz.cuda()).sum() + 0.3 * kl.sum()).backward()
+    assert rel(mom.grad, mr.grad) < 1e-5
+
+
+def test_latent_norm_train_eval_and_inverse():
+    from eo_vae_amd import ops
+    from oracle import eo_vae_cpu as O
+    bn = torch.nn.BatchNorm2d(128, affine=False)
+    O.det_fill(bn, seed=3)
+    rm, rv = bn.running_mean.clone().cuda(), bn.running_var.clone().cuda()
+    for training in (True, False):
+        bn.train(training)
+        z = hashed((3, 32, 8, 8), 20, 2.0) + 0.5
+        zr = z.clone().requires_grad_(True)
+        zp_r = bn(O.pixel_unshuffle2(zr))
+        out_r = O.pixel_shuffle2(zp_r * torch.sqrt(bn.running_var.view(1, -1, 1, 1) + 1e-4)
+                                 + bn.running_mean.view(1, -1, 1, 1))
+        go = hashed(tuple(out_r.shape), 21, 1.0)
+        out_r.backward(go)
+        zg = z.cuda().requires_grad_(True)
+        zp = ops.LatentNormFn.apply(zg, rm, rv, training, 1e-5, 0.1)
+        out = ops.LatentInvNormFn.apply(zp, rm, rv, 1e-4)
+        out.backward(go.cuda())
+        assert rel(zp, zp_r) < 1e-5 and rel(out, out_r) < 1e-5
+        assert rel(zg.grad, zr.grad) < 1e-4
+        assert rel(rm, bn.running_mean) < 1e-6 and rel(rv, bn.running_var) < 1e-6
+
+
+@pytest.mark.parametrize('kind', ['l1', 'char'])
+def test_pixel_losses(kind):
+    from eo_vae_amd import ops
+    from oracle import eo_vae_cpu as O
+    x = O.synthetic_batch(2, 12, 64, seed=3)
+    y = (x + 0.3 * hashed(tuple(x.shape), 5)).requires_grad_(True)
+    lr = F.l1_loss(y, x) if kind == 'l1' else O.charbonnier(y, x)
+    (2.5 * lr).backward()
+    yg = y.detach().cuda().requires_grad_(True)
+    lg = ops.l1_loss(yg, x.cuda()) if kind == 'l1' else ops.charbonnier_loss(yg, x.cuda())
+    (2.5 * lg).backward()
+    assert abs(lg.item() - lr.item()) <= 1e-6 * abs(lr.item())     # loss scalars: well inside 1e-4
+    assert rel(yg.grad, y.grad) < 1e-5
+
+
+@pytest.mark.parametrize('b,c,s', [(2, 3, 192), (2, 12, 256), (1, 2, 176)])
+def test_msssim_against_oracle(b, c, s):
+    """PARITY UNPINNED against the reference (torchmetrics absent): checked against the oracle's
+    restatement of the torchmetrics algorithm + known-answer properties."""
+    from eo_vae_amd import ops
+    from oracle import eo_vae_cpu as O
+    x = O.synthetic_batch(b, c, s, seed=11)
+    y0 = x + 0.15 * hashed(tuple(x.shape), 12) + 0.05
+    y = y0.clone().requires_grad_(True)
+    vr = O.msssim(y, x)
+    (1.0 - vr).backward()
+    yg = y0.cuda().requires_grad_(True)
+    vg = ops.msssim(yg, x.cuda())
+    (1.0 - vg).backward()
+    assert 0.0 < vr.item() < 1.0
+    assert abs(vg.item() - vr.item()) <= 1e-4 * abs(vr.item())     # loss scalar tolerance
+    assert rel(yg.grad, y.grad) < 2e-3
+    assert abs(ops.msssim(x.cuda(), x.cuda()).item() - 1.0) < 1e-5  # identical images -> 1
+    z = torch.randn(b, c, s, s, generator=torch.Generator().manual_seed(1)).cuda().requires_grad_(True)
+    vz = ops.msssim(z, -z.detach())                                  # anti-correlated: relu -> 0, zero grad
+    vz.backward()
+    assert vz.item() == 0.0 and float(z.grad.abs().max()) == 0.0
+
+
+def test_fused_adam_trajectory_matches_golden(golden):
+    """3 steps of forward/L1/backward/clip/Adam/LR-schedule on the tiny model (tiny_train fixture)."""
+    from oracle import eo_vae_cpu as O
+    from eo_vae_amd.autoencoder import EOFluxVAE, get_cosine_schedule_with_warmup
+    from eo_vae_amd.losses import EOConsistencyLoss
+    from eo_vae_amd.model import Decoder, Encoder
+    from eo_vae_amd.optim import FusedAdam
+    g = golden('tiny_train')
+    cfg = O.model_cfg(**O.TINY)
+    oracle = O.build_vae(cfg)
+    O.det_fill(oracle, seed=21)
+    m = EOFluxVAE(Encoder(**cfg['encoder']), Decoder(**cfg['decoder']),
+                  EOConsistencyLoss(pixel_weight=1.0, rec_loss_type='l1'), freeze_body=False,
+                  base_lr=1e-3, clip_grad=1.0)
+    m.load_state_dict(oracle.state_dict(), strict=False)
+    m.cuda().train()
+    params = [p for net in (m.encoder, m.decoder) for p in net.parameters()]
+    opt = FusedAdam(params, lr=1e-3)
+    sch = get_cosine_schedule_with_warmup(opt, 2, 6, 1e-3, 2e-4)
+
+    class Stub:
+        reducer = None
+
+        def log_metrics(self, *a, **k):
+            pass
+    m.attach(Stub(), [opt], [sch])
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A']).cuda()
+    for step in range(3):
+        batch = {'image': T(g[f'x{step}']).cuda(), 'wvs': wvs}
+        lr_before = opt.param_groups[0]['lr']
+        loss = m.training_step(batch, step, noise=T(g[f'eps{step}']).cuda())
+        m._global_step += 1
+        assert abs(lr_before - float(g[f'lr{step}'])) < 1e-12
+        assert abs(loss.item() - float(g[f'loss{step}'])) <= 1e-4 * float(g[f'loss{step}'])
+        assert abs(float(m.logged['train/grad_norm']) - float(g[f'gnorm{step}'])) <= 2e-3 * float(g[f'gnorm{step}'])
+    sd = m.state_dict()
+    assert rel(sd['bn.running_mean'], g['bn_running_mean']) < 1e-4
+    assert rel(sd['bn.running_var'], g['bn_running_var']) < 1e-4
+    assert int(sd['bn.num_batches_tracked']) == int(g['bn_batches'])
+    for k in [k for k in g if k.startswith('final.')]:
+        got = sd[k[6:]].reshape(-1)[:64].cpu()
+        assert (got - T(g[k])).abs().max().item() < 2.5e-3, k   # Adam amplifies round-off to ~lr
+
+
+def test_running_stats_against_golden(golden):
+    from eo_vae_amd.encode_latents import RunningStats
+    g = golden('running_stats')
+    rs = RunningStats(32, 'cuda')
+    for i in range(3):
+        rs.update(T(g[f'z{i}']).cuda())
+    d = rs.get_stats_dict()
+    for k in ['mean', 'var', 'std', 'min', 'max', 'count']:
+        assert rel(d[k], g[k]) < 1e-5, k
+
+
+def test_trainer_fit_smoke(tmp_path):
+    """train.py path end to end on a tiny model: YAML -> instantiate -> Trainer.fit -> checkpoint."""
+    import train as train_entry
+    from eo_vae_amd.config import load_config
+    cfg_path = tmp_path / 'tiny.yaml'
+    cfg_path.write_text('''
+experiment: {experiment_name: t, exp_dir: %s}
+model:
+  _target_: eo_vae.models.new_autoencoder.EOFluxVAE
+  freeze_body: False
+  base_lr: 1e-3
+  final_lr: 2e-4
+  warmup_epochs: 1
+  decay_end_epoch: ${trainer.max_epochs}
+  clip_grad: 1.0
+  loss_fn: {_target_: eo_vae.models.modules.consistency_loss.EOConsistencyLoss, rec_loss_type: char,
+            pixel_weight: 1.0, msssim_weight: 1.0, msssim_start_step: 2, kl_weight: 1.0e-6}
+  encoder: {_target_: eo_vae.models.Encoder, z_channels: 32, resolution: 192, in_channels: 3, ch: 32,
+            ch_mult: [1, 2, 2], num_res_blocks: 1, use_dynamic_ops: true,
+            dynamic_conv_kwargs: {num_layers: 1, wv_planes: 64}}
+  decoder: {_target_: eo_vae.models.Decoder, z_channels: 32, resolution: 192, out_ch: 3, ch: 32,
+            ch_mult: [1, 2, 2], num_res_blocks: 1, use_dynamic_ops: true,
+            dynamic_conv_kwargs: {num_layers: 1, wv_planes: 64}}
+datamodule:
+  _target_: eo_vae.datasets.terramesh_datamodule.TerraMeshDataModule
+  modalities: [S2L2A, S1RTC, S1GRD, S2RGB]
+  batch_size: 2
+  target_size: [192, 192]
+  train_steps: 4
+  val_steps: 2
+trainer: {_target_: lightning.Trainer, max_epochs: 1, limit_val_batches: 2, log_every_n_steps: 1}
+''' % tmp_path)
+    cfg = train_entry.create_experiment_dir(load_config(str(cfg_path)))
+    trainer, model = train_entry.run_experiment(cfg)
+    rows = [r for r in trainer.history if 'train/loss_total' in r]
+    assert len(rows) == 4 and all(np.isfinite(r['train/loss_total']) for r in rows)
+    assert 'train/loss_msssim' in rows[-1] and 'train/loss_msssim' not in rows[0]   # msssim_start_step
+    # logged after the scheduler step (reference :654-655,685): step 0 ran at lr 0 and logs 1/2000
+    assert abs(rows[0]['train/lr'] - 1e-3 / 2000) < 1e-12 and rows[1]['train/lr'] > rows[0]['train/lr']
+    import os
+    assert os.path.exists(os.path.join(cfg['experiment']['save_dir'], 'last.ckpt'))
+    assert os.path.exists(os.path.join(cfg['experiment']['save_dir'], 'metrics.csv'))
