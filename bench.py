@@ -30,6 +30,7 @@ F_STEP_PER_IMG = {3: 2.687e12, 12: 2.695e12}
 Q_STEP_PER_IMG = 9.90e9          # bytes / image
 Q_STEP_FIXED = 4.8e9             # bytes / step (weights, Adam, clip)
 PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA = 2500e12         # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_HBM = 8.0e12
 
 
@@ -148,7 +149,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -157,19 +158,30 @@ def main():
         achieved = k_flops / (k_ms * 1e-3) if k_ms > 0 else 0.0
         r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / args.batch)  # img/s per GPU at the HBM roof
         f_img = F_STEP_PER_IMG.get(C, 2.69e12)
+        prec = ops.CONV_PRECISION
+        if prec == 'f32':
+            peak, kname, dtype = PEAK_FP32_MFMA, 'conv_fwd_kernel<3,1,8> (3x3 conv fwd + data-grad)', 'f32'
+            path = 'fp32-input MFMA implicit GEMM (exact fp32)'
+        else:
+            peak = PEAK_BF16_MFMA
+            kname = 'conv3x3_bf16_kernel (3x3 conv fwd + data-grad, split-bf16 operands)'
+            dtype = 'bf16x3' if prec == 'bf16x3' else 'bf16'
+            path = ('split-bf16 implicit GEMM: x*w = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 '
+                    'accumulate (~2^-17 per product; 3 MFMAs per algorithmic one => frac <= 1/3)'
+                    if prec == 'bf16x3' else 'plain bf16 operands, fp32 accumulate (fast mode, below the parity bar)')
         out = {
             'metric': 'train-step images/sec (BxCx256x256)', 'value': round(ips, 3), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype,
             'data': 'synthetic (seeded low-res Gaussian field x8 bilinear + 0.25 noise, clamp[-2.5,8]); '
                     'random-init weights',
             'config': {'workload': f'cfg2: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, full '
                                    'train step (L1 + 1e-6 KL, clip 1.0, Adam, cosine-warmup LR)',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'conv_path': 'fp32-input MFMA implicit GEMM (exact fp32)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_kernel<3,1,8> (3x3 conv fwd + data-grad)',
-                         'achieved': round(achieved / 1e12, 2), 'peak': PEAK_FP32_MFMA / 1e12,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4),
+                       'conv_path': path},
+            'roofline': {'bound': 'mfma', 'kernel': kname,
+                         'achieved': round(achieved / 1e12, 2), 'peak': peak / 1e12,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': None, 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
             'step_flops_tflops': round(f_img * ips / world / 1e12, 2),

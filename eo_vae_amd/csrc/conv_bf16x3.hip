@@ -1,0 +1,498 @@
+// 3x3 stride-1 convolution as an implicit GEMM on the bf16 matrix cores with SPLIT-bf16
+// operands ("bf16x3"): every fp32 operand x is carried as hi = bf16(x), lo = bf16(x - hi) and
+//      x*w  ~=  hi_x*hi_w + hi_x*lo_w + lo_x*hi_w        (fp32 accumulation in the MFMA)
+// which keeps ~16 mantissa bits per operand (relative error ~2^-17 per product; the dropped
+// lo*lo term is 2^-18) -- enough to hold the 1e-3 parity bar through the ~60 stacked layers,
+// which plain bf16 (2^-9) cannot -- at 3 bf16 MFMAs per tile-step instead of 16 fp32-MFMA
+// equivalents (v_mfma_f32_32x32x16_bf16 runs 16x the rate of v_mfma_f32_32x32x2_f32).
+// NTERMS = 1 drops the two correction terms (plain bf16, fast / flagged mode).
+//
+// Same GEMM view and tile-loader index map (normal / nearest-x2 / zero-insert) as conv_f32.hip:
+//   D[co][pix] = sum_tap sum_ci Wp[tap][ci][co] * Xv[ci][pix @ tap]
+// Block = 512 threads = 8 waves, tile 128 co x (TH x 32) pixels, K streamed in 16-channel chunks.
+//   * X halo tile: fp32 NCHW -> registers -> split -> LDS as [pixel][16 ci] bf16 (hi and lo
+//     images).  A lane's MFMA B fragment (8 consecutive ci of one pixel) is ONE 16-byte
+//     ds_read_b128; 32 consecutive pixels of a row are 1 KiB contiguous => conflict-free, and a
+//     tap shift moves whole pixels, so every read stays 16-byte aligned.
+//   * W tile: pre-split, pre-tiled in global as [tap][chunk][co-block][hi|lo][128 co][16 ci];
+//     staged per ky-row phase (3 taps, 24 KiB) by straight 16-byte copies, double buffered.
+//   * per chunk: 3 phases x 3 taps x (2 x NI tiles) x NTERMS MFMAs per wave.
+#include "eovae_common.h"
+
+namespace {
+
+enum { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_ZINS = 3 };
+
+struct ConvBArgs {
+  const float* x;
+  const unsigned short* wp;  // split-packed weights (bf16 bits)
+  const float* bias;
+  const float* res;
+  float* y;
+  int N, Cin, Hin, Win, Cout, Hout, Wout;
+  int nchunk, ncob;
+  int mode;
+  int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int src_index3(int mode, int oy0, int ox0, int r, int c, int Hin, int Win) {
+  if (mode == MODE_NORMAL) {
+    int vy = oy0 + r - 1, vx = ox0 + c - 1;
+    return ((unsigned)vy < (unsigned)Hin && (unsigned)vx < (unsigned)Win) ? vy * Win + vx : -1;
+  } else if (mode == MODE_UP) {
+    int vy = oy0 + r - 1, vx = ox0 + c - 1;
+    return ((unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win))
+               ? (vy >> 1) * Win + (vx >> 1)
+               : -1;
+  } else {  // MODE_ZINS
+    int vy = oy0 + r - 2, vx = ox0 + c - 2;
+    bool ok = (unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win) &&
+              !((vy | vx) & 1);
+    return ok ? (vy >> 1) * Win + (vx >> 1) : -1;
+  }
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+template <int TH, int NTERMS>
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
+  constexpr int TW = 32, BM = 128, KC = 16;
+  constexpr int XH = TH + 2, XW = TW + 2, NPX = XH * XW;
+  constexpr int NI = TH / 4;                    // pixel-row tiles per wave
+  constexpr int XBYTES = NPX * KC * 2;          // one halo image (hi or lo)
+  constexpr int WTAP = 2 * BM * KC * 2;         // hi+lo tile of one tap: 8 KiB
+  constexpr int WPHASE = 3 * WTAP;              // one ky row of taps: 24 KiB
+  constexpr int XTASKS = NPX * 2;               // (pixel, 8-channel octet)
+  constexpr int XPT = (XTASKS + 511) / 512;
+  constexpr int OFF_XLO = XBYTES, OFF_W = 2 * XBYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XBYTES + 2 * WPHASE];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int cob = b % a.ncob;
+  b /= a.ncob;
+  const int tx = b % a.tiles_x;
+  b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int wco = (wave & 1) * 64, wrow = (wave >> 1) * NI;
+  const size_t in_plane = (size_t)a.Hin * a.Win;
+  const float* xn = a.x + (size_t)n * a.Cin * in_plane;
+
+  float xr[XPT][8];
+  f32x4 wr[3];
+
+  auto load_x = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int t = tid + i * 512;
+      const int g = t / NPX, pix = t - g * NPX;
+      const int rr = pix / XW, cc = pix - rr * XW;
+      const int si = (t < XTASKS) ? src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win) : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = c0 + g * 8 + j;
+        xr[i][j] = (si >= 0 && ci < a.Cin) ? xn[(size_t)ci * in_plane + si] : 0.f;
+      }
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int t = tid + i * 512;
+      if (t < XTASKS) {
+        const int g = t / NPX, pix = t - g * NPX;
+        bf16x8 hi, lo;
+        split8(xr[i], hi, lo);
+        *reinterpret_cast<bf16x8*>(smem + pix * 32 + g * 16) = hi;
+        if (NTERMS == 3) *reinterpret_cast<bf16x8*>(smem + OFF_XLO + pix * 32 + g * 16) = lo;
+      }
+    }
+  };
+  // phase p = chunk*3 + ky : taps ky*3 .. ky*3+2 of channel chunk `chunk`
+  auto load_w = [&](int chunk, int ky) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int u = tid + i * 512;        // 16-byte unit in [0, 1536)
+      const int tl = u >> 9, within = u & 511;
+      const size_t tile = ((size_t)((ky * 3 + tl) * a.nchunk + chunk) * a.ncob + cob);
+      wr[i] = *reinterpret_cast<const f32x4*>(
+          reinterpret_cast<const unsigned char*>(a.wp) + tile * WTAP + within * 16);
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int u = tid + i * 512;
+      *reinterpret_cast<f32x4*>(smem + OFF_W + buf * WPHASE + u * 16) = wr[i];
+    }
+  };
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  load_x(0);
+  load_w(0, 0);
+  store_x();
+  store_w(0);
+  __syncthreads();
+
+  const int nphase = a.nchunk * 3;
+  for (int p = 0; p < nphase; ++p) {
+    const int chunk = p / 3, ky = p - chunk * 3;
+    const int buf = p & 1;
+    if (p + 1 < nphase) load_w((p + 1) / 3, (p + 1) % 3);
+    if (ky == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
+
+    const unsigned char* wb = smem + OFF_W + buf * WPHASE;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      bf16x8 ahi[2], alo[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = kx * WTAP + ((wco + i * 32 + r) * KC + 8 * h) * 2;
+        ahi[i] = *reinterpret_cast<const bf16x8*>(wb + off);
+        if (NTERMS == 3) alo[i] = *reinterpret_cast<const bf16x8*>(wb + off + BM * KC * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int pix = (wrow + j + ky) * XW + r + kx;
+        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(smem + pix * 32 + h * 16);
+        bf16x8 blo;
+        if (NTERMS == 3) blo = *reinterpret_cast<const bf16x8*>(smem + OFF_XLO + pix * 32 + h * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (NTERMS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo, acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+
+    if (p + 1 < nphase) store_w(buf ^ 1);  // other buffer: last read in phase p-1, fenced below
+    if (ky == 2 && chunk + 1 < a.nchunk) {
+      __syncthreads();  // every wave has finished reading this chunk's halo tile
+      store_x();
+    }
+    __syncthreads();
+  }
+
+  const size_t out_plane = (size_t)a.Hout * a.Wout;
+  const int ox = ox0 + r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = cob * BM + wco + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (co >= a.Cout) continue;
+      const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int oy = oy0 + wrow + j;
+        if (oy < a.Hout && ox < a.Wout) {
+          const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wout + ox;
+          float v = acc[i][j][q] + bias;
+          if (a.res) v += a.res[o];
+          a.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient with split-bf16 operands:
+//   dWp[tap][co][ci] += sum_{n,pix} dY[n][co][pix] * Xv[n][ci][pix @ tap]       (K = pixels)
+// Block = 8 waves, tile 128 co x 64 ci x 9 taps; wave = (32 co) x (32 ci) x 9 accumulator tiles.
+// Both operands have K = pixel, which is the contiguous NCHW axis, but a tap shift of one pixel
+// would break the 16-byte alignment of a K-contiguous fragment read.  So both tiles are staged
+// channel-contiguous ([pixel][32 channels], 64-byte rows: a tap shift moves whole rows) and the
+// fragments are gathered with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group,
+// delivered pixel-major per lane); 4 consecutive pixel rows = 256 contiguous bytes => no bank
+// conflicts.  Pixel tiles of 2 x 32 are double buffered in LDS; the next tile is loaded one
+// k-step (16 pixels) at a time behind the current k-step's 27 MFMAs.
+// ---------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+  using lds4 = __attribute__((address_space(3))) s16x4;
+  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p));
+  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p + 4 * 64));
+  const s16x8 f = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, f);
+}
+
+struct WgBArgs {
+  const float* x;
+  const float* dy;
+  float* dwp;  // [9][Cout][Cin] fp32, pre-zeroed
+  int N, Cin, Hin, Win, Cout, Hout, Wout;
+  int mode;
+  int tiles_x, tiles_y, ntiles, ncib;
+};
+
+template <int NTERMS>
+__global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
+  constexpr int PW = 32, XW = 34, NXP = 4 * XW;          // 2 output rows + halo
+  constexpr int DPART = 4 * 64 * 64;                      // [4 co-tiles][64 pix][32 co] bf16
+  constexpr int XPART = 2 * NXP * 64;                     // [2 ci-tiles][136 pix][32 ci] bf16
+  constexpr int OFF_X = 2 * DPART;
+  constexpr int BUF = 2 * DPART + 2 * XPART;
+  constexpr int XQ = NXP * 8 / 4;                         // X tasks per k-step (272)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  const int ct = wave & 3, cih = wave >> 2;
+  const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
+  const size_t in_plane = (size_t)a.Hin * a.Win, out_plane = (size_t)a.Hout * a.Wout;
+  // per-lane byte offset inside a [pixel][32 ch] image for a transposed 4x16 block read
+  const int tr_lane = (8 * (g >> 1) + lq) * 64 + (16 * (g & 1) + 4 * lp) * 2;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  float dyr[8], xr[8];
+  auto issue = [&](int tile, int ks) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty * 2, ox0 = tx * PW;
+    if (tid < 256) {
+      const int pixl = tid & 15, oct = tid >> 4;
+      const int oy = oy0 + (ks >> 1), ox = ox0 + 16 * (ks & 1) + pixl;
+      const bool ok = oy < a.Hout && ox < a.Wout;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int co = cob * 128 + oct * 8 + j;
+        dyr[j] = (ok && co < a.Cout)
+                     ? a.dy[((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wout + ox]
+                     : 0.f;
+      }
+    }
+    if (tid < XQ) {
+      const int t2 = ks * XQ + tid;
+      const int oct = t2 / NXP, pix = t2 - oct * NXP;
+      const int rr = pix / XW, cc = pix - rr * XW;
+      const int si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = cib * 64 + oct * 8 + j;
+        xr[j] = (si >= 0 && ci < a.Cin) ? a.x[((size_t)n * a.Cin + ci) * in_plane + si] : 0.f;
+      }
+    }
+  };
+  auto commit = [&](int buf, int ks) {
+    unsigned char* base = smem + buf * BUF;
+    if (tid < 256) {
+      const int pixl = tid & 15, oct = tid >> 4;
+      bf16x8 hi, lo;
+      split8(dyr, hi, lo);
+      const int off = (oct >> 2) * 4096 + (ks * 16 + pixl) * 64 + (oct & 3) * 16;
+      *reinterpret_cast<bf16x8*>(base + off) = hi;
+      if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + DPART + off) = lo;
+    }
+    if (tid < XQ) {
+      const int t2 = ks * XQ + tid;
+      const int oct = t2 / NXP, pix = t2 - oct * NXP;
+      bf16x8 hi, lo;
+      split8(xr, hi, lo);
+      const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (oct & 3) * 16;
+      *reinterpret_cast<bf16x8*>(base + off) = hi;
+      if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + XPART + off) = lo;
+    }
+  };
+
+  int tile = blockIdx.y;
+  if (tile < a.ntiles) {
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {
+      issue(tile, ks);
+      commit(0, ks);
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; tile < a.ntiles; tile += gridDim.y) {
+    const int next = tile + gridDim.y;
+    const bool has_next = next < a.ntiles;
+    const unsigned char* base = smem + cur * BUF;
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {
+      if (has_next) issue(next, ks);
+      const int row = ks >> 1, x0 = 16 * (ks & 1);
+      const unsigned char* ap = base + ct * 4096 + ks * 16 * 64 + tr_lane;
+      const bf16x8 ahi = tr_frag(ap);
+      bf16x8 alo;
+      if (NTERMS == 3) alo = tr_frag(ap + DPART);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned char* bp =
+            base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64 + tr_lane;
+        const bf16x8 bhi = tr_frag(bp);
+        if (NTERMS == 3) {
+          const bf16x8 blo = tr_frag(bp + XPART);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[tap], 0, 0, 0);
+        }
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[tap], 0, 0, 0);
+      }
+      if (has_next) commit(cur ^ 1, ks);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int ci = cib * 64 + cih * 32 + r;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = cob * 128 + ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (co < a.Cout) atomicAdd(&a.dwp[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[tap][q]);
+      }
+    }
+  }
+}
+
+// w[Cout][Cin][9] fp32 -> [tap][chunk][cob][hi|lo][128][16] bf16 bits (zero padded)
+//   flip = 0: k = ci, m = co;  flip = 1 (data gradient): k = co, m = ci, taps reversed
+__global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                  int Cout, int Cin, int nchunk, int ncob, int flip, float scale) {
+  const size_t total = (size_t)9 * nchunk * ncob * 128 * 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int kin = i & 15;
+    size_t t = i >> 4;
+    const int min_ = t & 127;
+    t >>= 7;
+    const int cob = t % ncob;
+    t /= ncob;
+    const int chunk = t % nchunk;
+    const int tap = t / nchunk;
+    const int k = chunk * 16 + kin, m = cob * 128 + min_;
+    const int co = flip ? k : m, ci = flip ? m : k;
+    const int st = flip ? 8 - tap : tap;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + st] * scale;
+    const __bf16 hb = (__bf16)v;
+    const __bf16 lb = (__bf16)(v - (float)hb);
+    const size_t tile = ((size_t)(tap * nchunk + chunk) * ncob + cob) * (2 * 128 * 16);
+    wp[tile + min_ * 16 + kin] = __builtin_bit_cast(unsigned short, hb);
+    wp[tile + 128 * 16 + min_ * 16 + kin] = __builtin_bit_cast(unsigned short, lb);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// number of bf16 elements of the split-packed weight buffer for a 3x3 layer
+size_t eovae_conv3x3_bf16_packed_elems(int Cout, int Cin, int flip) {
+  const int k = flip ? Cout : Cin, m = flip ? Cin : Cout;
+  return (size_t)9 * cdiv(k, 16) * cdiv(m, 128) * 2 * 128 * 16;
+}
+
+int eovae_conv3x3_bf16_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale,
+                            void* stream) {
+  EOVAE_CHECK_ARG(w && wp && Cout > 0 && Cin > 0, "conv3x3_bf16_pack: bad argument");
+  const int k = flip ? Cout : Cin, m = flip ? Cin : Cout;
+  const int nchunk = cdiv(k, 16), ncob = cdiv(m, 128);
+  size_t total = (size_t)9 * nchunk * ncob * 128 * 16;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     (unsigned short*)wp, Cout, Cin, nchunk, ncob, flip, scale);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_bf16_pack");
+  return EOVAE_OK;
+}
+
+// 3x3 stride-1 conv (modes NORMAL / UP / ZINS) with split-bf16 operands.
+//   precision: 3 = bf16x3 (fp32-grade), 1 = plain bf16
+// (Cin, Cout) = GEMM K / M channel counts of this call (swapped + flip-packed for a data gradient).
+int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, const float* residual,
+                           float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                           int mode, int precision, void* stream) {
+  EOVAE_CHECK_ARG(x && wp && y, "conv3x3_bf16_fwd: null pointer");
+  EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_bf16_fwd: bad shape");
+  EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP || mode == MODE_ZINS,
+                  "conv3x3_bf16_fwd: mode %d unsupported", mode);
+  EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_fwd: precision %d", precision);
+  const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;
+  EOVAE_CHECK_ARG(Hout == eh && Wout == ew, "conv3x3_bf16_fwd: output %dx%d does not match mode %d",
+                  Hout, Wout, mode);
+  ConvBArgs a;
+  a.x = x; a.wp = (const unsigned short*)wp; a.bias = bias; a.res = residual; a.y = y;
+  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
+  a.nchunk = cdiv(Cin, 16); a.ncob = cdiv(Cout, 128); a.mode = mode;
+  a.tiles_x = cdiv(Wout, 32);
+  hipStream_t st = (hipStream_t)stream;
+  // 16-row tiles when that still fills the chip (>= 2 blocks per CU), else 8-row tiles
+  const long long blocks16 = (long long)N * cdiv(Hout, 16) * a.tiles_x * a.ncob;
+  if (blocks16 >= 512) {
+    a.tiles_y = cdiv(Hout, 16);
+    dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
+    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 3>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 1>), grid, dim3(512), 0, st, a);
+  } else {
+    a.tiles_y = cdiv(Hout, 8);
+    dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
+    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 3>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 1>), grid, dim3(512), 0, st, a);
+  }
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_bf16_fwd");
+  return EOVAE_OK;
+}
+
+// dwp[9][Cout][Cin] += dY (x) Xv with split-bf16 operands (modes NORMAL / UP of the forward layer)
+int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
+                             int Win, int Cout, int Hout, int Wout, int mode, int precision,
+                             void* stream) {
+  EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_bf16_wgrad: null pointer");
+  EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_bf16_wgrad: mode %d unsupported", mode);
+  EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_wgrad: precision %d", precision);
+  WgBArgs a;
+  a.x = x; a.dy = dy; a.dwp = dwp;
+  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
+  a.mode = mode;
+  a.tiles_x = cdiv(Wout, 32); a.tiles_y = cdiv(Hout, 2);
+  a.ntiles = N * a.tiles_x * a.tiles_y;
+  a.ncib = cdiv(Cin, 64);
+  const int ncob = cdiv(Cout, 128);
+  int split = 512 / (a.ncib * ncob);
+  if (split < 1) split = 1;
+  if (split > a.ntiles) split = a.ntiles;
+  dim3 grid(a.ncib * ncob, split);
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1>), grid, dim3(512), 0, st, a);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_bf16_wgrad");
+  return EOVAE_OK;
+}
+
+}  // extern "C"

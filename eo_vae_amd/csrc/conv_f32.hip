@@ -319,21 +319,36 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
   }
 }
 
-// db[c] = sum_{n,hw} dy[n][c][hw]; one block per channel, double accumulation across waves
+// db[c] += sum over a slice of (n, hw); grid (C, nsplit), float4 loads, one atomic per block
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
                                                         float* __restrict__ db, int N, int C,
                                                         int HW) {
   const int c = blockIdx.x;
+  const int hw4 = HW >> 2;                       // float4 units per plane (HW % 4 == 0 path)
+  const bool vec = (HW & 3) == 0;
+  const long long units = (long long)N * (vec ? hw4 : HW);
+  const long long per = (units + gridDim.y - 1) / gridDim.y;
+  const long long beg = per * blockIdx.y;
+  long long end = beg + per;
+  if (end > units) end = units;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float* p = dy + ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+  if (vec) {
+    for (long long u = beg + threadIdx.x; u < end; u += 256) {
+      const int n = (int)(u / hw4), q = (int)(u - (long long)n * hw4);
+      const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)n * C + c) * HW + 4 * (size_t)q);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long u = beg + threadIdx.x; u < end; u += 256) {
+      const int n = (int)(u / HW), q = (int)(u - (long long)n * HW);
+      s += dy[((size_t)n * C + c) * HW + q];
+    }
   }
   __shared__ double red[4];
   double d = wave_sum_d((double)s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) db[c] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) atomicAdd(&db[c], (float)(red[0] + red[1] + red[2] + red[3]));
 }
 
 // adjoint of nearest x2 upsampling: dx[n][c][y][x] = sum of the 2x2 block of du
@@ -460,7 +475,13 @@ int eovae_conv_unpack_wgrad(const float* dwp, float* dw, int Cout, int Cin, int 
 
 int eovae_bias_grad(const float* dy, float* db, int N, int C, int HW, void* stream) {
   EOVAE_CHECK_ARG(dy && db && N > 0 && C > 0 && HW > 0, "bias_grad: bad argument");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, N, C, HW);
+  long long work = (long long)N * HW;
+  int split = (int)((work + 16383) / 16384);
+  if (split < 1) split = 1;
+  if (split > 64) split = 64;
+  while (split > 1 && (long long)C * split > 4096) split >>= 1;
+  hipMemsetAsync(db, 0, (size_t)C * sizeof(float), (hipStream_t)stream);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, split), dim3(256), 0, (hipStream_t)stream, dy, db, N, C, HW);
   EOVAE_CHECK_LAUNCH("eovae_bias_grad");
   return EOVAE_OK;
 }

@@ -5,6 +5,7 @@ forward/backward below is one or more calls into libeovae_hip.so on the current 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -99,6 +100,38 @@ def conv_raw(x, wp, kp, mp, bias, residual, cout, ks, mode, out_scale=1.0):
     return y
 
 
+# Arithmetic of the 3x3 stride-1 convolutions (99 % of the step's flops):
+#   'f32'    exact fp32 on v_mfma_f32_32x32x2_f32 (csrc/conv_f32.hip)
+#   'bf16x3' split-bf16, 3 bf16 MFMAs per step, fp32-grade (~2^-17)  (csrc/conv_bf16x3.hip)
+#   'bf16'   plain bf16 operands, fp32 accumulate (fast mode; does NOT meet the 1e-3 parity bar)
+CONV_PRECISION = os.environ.get('EOVAE_CONV_PRECISION', 'bf16x3')
+_PREC = {'bf16x3': 3, 'bf16': 1}
+
+
+def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
+    """3x3 stride-1 conv / data-gradient on the bf16 matrix cores (weight in PyTorch layout)."""
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(cout, cin, int(flip)), dtype=torch.bfloat16,
+                     device=x.device)
+    L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(weight), L.ptr(wp), cout, cin, int(flip), 1.0, L.stream()),
+            'eovae_conv3x3_bf16_pack')
+    n, cin_g, h, w = x.shape
+    ho, wo = _out_hw(h, w, mode)
+    y = torch.empty(n, cout_gemm, ho, wo, dtype=torch.float32, device=x.device)
+    timed = CONV3X3_TIMER is not None
+    if timed:
+        pix = (ho * wo) // 4 if mode == MODE_ZINS else ho * wo
+        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout_gemm * cin_g * 9)
+        ev0.record()
+    L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
+                                       cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION],
+                                       L.stream()), 'eovae_conv3x3_bf16_fwd')
+    if timed:
+        ev1.record()
+    return y
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv(x, w) + b (+ residual); mode in {'normal','down','up'} (see csrc/conv_f32.hip)."""
 
@@ -110,9 +143,13 @@ class Conv2dFn(torch.autograd.Function):
         cout, cin, ks, _ = weight.shape
         if x.shape[1] != cin:
             raise L.EovaeError(f'conv2d: input has {x.shape[1]} channels, weight expects {cin}')
-        wp, kp, mp = pack_weights(weight, m, False)
         res = _c(residual) if residual is not None else None
-        y = conv_raw(x, wp, kp, mp, _c(bias) if bias is not None else None, res, cout, ks, m)
+        bias_c = _c(bias) if bias is not None else None
+        if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
+            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False)
+        else:
+            wp, kp, mp = pack_weights(weight, m, False)
+            y = conv_raw(x, wp, kp, mp, bias_c, res, cout, ks, m)
         ctx.save_for_backward(x, weight)
         ctx.mode, ctx.has_bias, ctx.has_res = m, bias is not None, residual is not None
         return y
@@ -126,7 +163,19 @@ class Conv2dFn(torch.autograd.Function):
         n, _, h, w = x.shape
         lib = L.load()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ks == 3 and CONV_PRECISION != 'f32':
+            if m == MODE_NORMAL:
+                dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_NORMAL, True)
+            elif m == MODE_DOWN:
+                dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_ZINS, True)
+                if dx.shape[2] != h or dx.shape[3] != w:
+                    raise L.EovaeError('conv2d(down): odd spatial sizes are not supported')
+            else:
+                du = conv3x3_lowp(dy, weight, None, None, cin, MODE_NORMAL, True)
+                dx = torch.empty_like(x)
+                L.check(lib.eovae_upsample2x_bwd(L.ptr(du), L.ptr(dx), n, cin, h, w, L.stream()),
+                        'eovae_upsample2x_bwd')
+        elif ctx.needs_input_grad[0]:
             wp, kp, mp = pack_weights(weight, m, True)
             if m == MODE_NORMAL:
                 dx = conv_raw(dy, wp, kp, mp, None, None, cin, ks, MODE_NORMAL)
@@ -141,9 +190,14 @@ class Conv2dFn(torch.autograd.Function):
                         'eovae_upsample2x_bwd')
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros(ks * ks * cout * cin, dtype=torch.float32, device=x.device)
-            L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
-                                           dy.shape[2], dy.shape[3], ks, m, L.stream()),
-                    'eovae_conv2d_wgrad')
+            if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
+                L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
+                                                     dy.shape[2], dy.shape[3], m, _PREC[CONV_PRECISION],
+                                                     L.stream()), 'eovae_conv3x3_bf16_wgrad')
+            else:
+                L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
+                                               dy.shape[2], dy.shape[3], ks, m, L.stream()),
+                        'eovae_conv2d_wgrad')
             dw = torch.empty_like(weight)
             L.check(lib.eovae_conv_unpack_wgrad(L.ptr(dwp), L.ptr(dw), cout, cin, ks, L.stream()),
                     'eovae_conv_unpack_wgrad')

@@ -50,6 +50,20 @@ int eovae_conv_pack_weights(const float* w, float* wp, int Cout, int Cin, int KS
 int eovae_conv2d_fwd(const float* x, const float* wp, const float* bias, const float* residual,
                      float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
                      int KS, int mode, int KP, int MP, float out_scale, void* stream);
+/* Split-bf16 ("bf16x3") variant of the 3x3 stride-1 convolution (csrc/conv_bf16x3.hip): operands
+ * carried as hi+lo bf16 pairs, 3 bf16 MFMAs per tile step, fp32 accumulate (~2^-17 per product).
+ * precision 3 = bf16x3 (fp32-grade), 1 = plain bf16.  Modes 0 (NORMAL), 2 (UP), 3 (ZINS).
+ * Weights are consumed split-packed: [tap][Cin/16][Cout/128][hi|lo][128][16] bf16. */
+size_t eovae_conv3x3_bf16_packed_elems(int Cout, int Cin, int flip);
+int eovae_conv3x3_bf16_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale,
+                            void* stream);
+int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, const float* residual,
+                           float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                           int mode, int precision, void* stream);
+/* split-bf16 weight gradient: dwp[9][Cout][Cin] += dy (x) x, modes 0 / 2 of the forward layer */
+int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
+                             int Win, int Cout, int Hout, int Wout, int mode, int precision,
+                             void* stream);
 /* dwp[tap][Cout][Cin] += sum_{n,pix} dy * x (mode 0/1/2 of the FORWARD layer); caller zero-fills */
 int eovae_conv2d_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
                        int Win, int Cout, int Hout, int Wout, int KS, int mode, void* stream);

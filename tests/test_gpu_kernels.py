@@ -59,9 +59,13 @@ def test_conv2d_fwd_bwd(n, cin, cout, h, w, ks, mode):
     gy = hashed(tuple(yr.shape), 4, 1.0)
     (yr + rr).backward(gy)
     xg, wg, bg, rg = [t.cuda().requires_grad_(True) for t in (x, wt, b, res)]
-    yg = ops.conv2d(xg, wg, bg, rg, mode)
-    yg.backward(gy.cuda())
-    torch.cuda.synchronize()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f32'     # exact-fp32 MFMA kernels (conv_f32.hip)
+    try:
+        yg = ops.conv2d(xg, wg, bg, rg, mode)
+        yg.backward(gy.cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_PRECISION = old
     assert rel_err(yg, yr + rr) < 2e-6
     assert rel_err(xg.grad, xr.grad) < 1e-5
     assert rel_err(wg.grad, wr.grad) < 2e-5      # atomically accumulated split-K partial sums
@@ -100,3 +104,36 @@ def test_fails_loudly_on_cpu_tensor():
     from eo_vae_amd.lib import EovaeError
     with pytest.raises(EovaeError):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+LOWP_CASES = [(2, 32, 32, 16, 16, 'normal'), (1, 128, 128, 64, 64, 'normal'), (2, 3, 128, 24, 40, 'normal'),
+              (2, 128, 3, 24, 40, 'normal'), (1, 13, 128, 9, 33, 'normal'), (1, 256, 64, 16, 16, 'normal'),
+              (4, 512, 512, 32, 32, 'normal'), (2, 32, 32, 16, 16, 'down'), (2, 32, 32, 8, 8, 'up'),
+              (1, 256, 256, 32, 32, 'up')]
+
+
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('n,cin,cout,h,w,mode', LOWP_CASES)
+def test_conv3x3_split_bf16(n, cin, cout, h, w, mode, precision, tol):
+    """bf16x3 (hi*hi + hi*lo + lo*hi on the bf16 MFMA) must be fp32-grade: ~2^-17 per product;
+    plain bf16 is the flagged fast mode (2^-9) and only has to be sane."""
+    from eo_vae_amd import ops
+    x = hashed((n, cin, h, w), 1, 1.0)
+    wt = hashed((cout, cin, 3, 3), 2, 1.0 / (cin * 9) ** 0.5)
+    b = hashed((cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, br, mode)
+    gy = hashed(tuple(yr.shape), 4, 1.0)
+    yr.backward(gy)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = precision
+    try:
+        xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, wt, b)]
+        yg = ops.conv2d(xg, wg, bg, None, mode)
+        yg.backward(gy.cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_PRECISION = old
+    assert rel_err(yg, yr) < tol
+    assert rel_err(xg.grad, xr.grad) < tol
+    assert rel_err(wg.grad, wr.grad) < max(tol, 2e-5)
