@@ -273,24 +273,27 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
-  float dyr[8], xr[8];
-  auto issue = [&](int tile, int ks) {
+  // staging registers: a quarter tile is issued before a k-step's 27 MFMAs and committed to
+  // the other LDS buffer after them.  dY is staged by ALL 512 threads (4 channels x 1 pixel
+  // each), the X halo by the first 272 (8 channels x 1 pixel).
+  float dyr[1][4], xr[1][8];
+  auto issue = [&](int tile, int ks, float (&dq)[4], float (&xq)[8]) {
     int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int oy0 = ty * 2, ox0 = tx * PW;
-    if (tid < 256) {
-      const int pixl = tid & 15, oct = tid >> 4;
+    {
+      const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels
       const int oy = oy0 + (ks >> 1), ox = ox0 + 16 * (ks & 1) + pixl;
       const bool ok = oy < a.Hout && ox < a.Wout;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int co = cob * 128 + oct * 8 + j;
-        dyr[j] = (ok && co < a.Cout)
-                     ? a.dy[((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wout + ox]
-                     : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const int co = cob * 128 + quad * 4 + j;
+        dq[j] = (ok && co < a.Cout)
+                    ? a.dy[((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wout + ox]
+                    : 0.f;
       }
     }
     if (tid < XQ) {
@@ -301,28 +304,54 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ci = cib * 64 + oct * 8 + j;
-        xr[j] = (si >= 0 && ci < a.Cin) ? a.x[((size_t)n * a.Cin + ci) * in_plane + si] : 0.f;
+        xq[j] = (si >= 0 && ci < a.Cin) ? a.x[((size_t)n * a.Cin + ci) * in_plane + si] : 0.f;
       }
     }
   };
-  auto commit = [&](int buf, int ks) {
+  auto commit = [&](int buf, int ks, const float (&dq)[4], const float (&xq)[8]) {
     unsigned char* base = smem + buf * BUF;
-    if (tid < 256) {
-      const int pixl = tid & 15, oct = tid >> 4;
-      bf16x8 hi, lo;
-      split8(dyr, hi, lo);
-      const int off = (oct >> 2) * 4096 + (ks * 16 + pixl) * 64 + (oct & 3) * 16;
-      *reinterpret_cast<bf16x8*>(base + off) = hi;
-      if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + DPART + off) = lo;
+    {
+      const int pixl = tid & 15, quad = tid >> 4;
+      typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+      bf16x4v hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)dq[j];
+        hi[j] = hb;
+        lo[j] = (__bf16)(dq[j] - (float)hb);
+      }
+      const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (quad & 7) * 8;
+      *reinterpret_cast<bf16x4v*>(base + off) = hi;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4v*>(base + DPART + off) = lo;
     }
     if (tid < XQ) {
       const int t2 = ks * XQ + tid;
       const int oct = t2 / NXP, pix = t2 - oct * NXP;
       bf16x8 hi, lo;
-      split8(xr, hi, lo);
+      split8(xq, hi, lo);
       const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (oct & 3) * 16;
       *reinterpret_cast<bf16x8*>(base + off) = hi;
       if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + XPART + off) = lo;
+    }
+  };
+  auto compute = [&](const unsigned char* base, int ks) {
+    const int row = ks >> 1, x0 = 16 * (ks & 1);
+    const unsigned char* ap = base + ct * 4096 + ks * 16 * 64 + tr_lane;
+    const bf16x8 ahi = tr_frag(ap);
+    bf16x8 alo;
+    if (NTERMS == 3) alo = tr_frag(ap + DPART);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const unsigned char* bp =
+          base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64 + tr_lane;
+      const bf16x8 bhi = tr_frag(bp);
+      if (NTERMS == 3) {
+        const bf16x8 blo = tr_frag(bp + XPART);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[tap], 0, 0, 0);
+      }
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[tap], 0, 0, 0);
     }
   };
 
@@ -330,8 +359,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   if (tile < a.ntiles) {
 #pragma unroll 1
     for (int ks = 0; ks < 4; ++ks) {
-      issue(tile, ks);
-      commit(0, ks);
+      issue(tile, ks, dyr[0], xr[0]);
+      commit(0, ks, dyr[0], xr[0]);
     }
   }
   __syncthreads();
@@ -342,26 +371,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
     const unsigned char* base = smem + cur * BUF;
 #pragma unroll 1
     for (int ks = 0; ks < 4; ++ks) {
-      if (has_next) issue(next, ks);
-      const int row = ks >> 1, x0 = 16 * (ks & 1);
-      const unsigned char* ap = base + ct * 4096 + ks * 16 * 64 + tr_lane;
-      const bf16x8 ahi = tr_frag(ap);
-      bf16x8 alo;
-      if (NTERMS == 3) alo = tr_frag(ap + DPART);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        const unsigned char* bp =
-            base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64 + tr_lane;
-        const bf16x8 bhi = tr_frag(bp);
-        if (NTERMS == 3) {
-          const bf16x8 blo = tr_frag(bp + XPART);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[tap], 0, 0, 0);
-        }
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[tap], 0, 0, 0);
-      }
-      if (has_next) commit(cur ^ 1, ks);
+      if (has_next) issue(next, ks, dyr[0], xr[0]);
+      compute(base, ks);
+      if (has_next) commit(cur ^ 1, ks, dyr[0], xr[0]);
     }
     __syncthreads();
     cur ^= 1;
