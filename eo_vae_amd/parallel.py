@@ -27,8 +27,11 @@ def init_distributed(backend: str | None = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'  # 'nccl' IS RCCL on ROCm
+        if backend is None:  # EOVAE_DIST_BACKEND=gloo: single-GPU rehearsal of the N>1 path
+            backend = os.environ.get('EOVAE_DIST_BACKEND') or \
+                ('nccl' if torch.cuda.is_available() else 'gloo')  # 'nccl' IS RCCL on ROCm
+        if os.environ.get('EOVAE_ALL_RANKS_ONE_GPU') == '1':
+            local = 0
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -1,0 +1,33 @@
+"""Per-layer timing of the 3x3 conv kernels at the real layer shapes (B=16): algorithmic TFLOP/s.
+Calls the C-ABI wrappers directly (no autograd) so only kernel time is measured."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from eo_vae_amd import ops, lib as L
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+shapes = [(128, 128, 256), (256, 256, 128), (512, 512, 64), (512, 512, 32), (256, 128, 256), (512, 256, 128)]
+B = 16
+lib = L.load()
+for prec in sys.argv[1:] or ['bf16x3']:
+    ops.CONV_PRECISION = prec
+    p = ops._PREC[prec]
+    for cin, cout, hw in shapes:
+        x = torch.randn(B, cin, hw, hw, device='cuda')
+        w = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
+        dy = torch.randn(B, cout, hw, hw, device='cuda')
+        flops = 2.0 * B * hw * hw * cin * cout * 9
+        wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(cout, cin, 0), dtype=torch.bfloat16, device='cuda')
+        lib.eovae_conv3x3_bf16_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream())
+        y = torch.empty_like(dy)
+        t_f = timeit(lambda: lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, cin, hw, hw, cout, hw, hw, 0, p, L.stream()))
+        dwp = torch.zeros(9 * cout * cin, device='cuda')
+        t_w = timeit(lambda: lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), B, cin, hw, hw, cout, hw, hw, 0, p, L.stream()))
+        print(f'{prec:7s} {cin:4d}->{cout:4d} @{hw:3d}^2  fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF', flush=True)
