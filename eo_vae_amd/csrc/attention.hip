@@ -191,37 +191,55 @@ int eovae_softmax_bwd_rows(const float* p, float* dp, long long rows, int n, voi
   return EOVAE_OK;
 }
 
+int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, const float* res,
+                      int batch, int M, int N, int K, long long sam, long long sak, long long sbk,
+                      long long sbn, long long scm, long long scn, long long batA, long long batB,
+                      long long batC, float alpha, int ksplit, int atomic, int precision,
+                      void* stream);
+
+// precision 0: exact fp32 MFMA GEMM; 1 / 3: bf16 / split-bf16 GEMM (csrc/gemm_bf16x3.hip)
+static int gemm_any(int precision, const float* A, const float* B, float* Cm, int batch, int M, int N,
+                    int K, long long sam, long long sak, long long sbk, long long sbn, long long scm,
+                    long long scn, long long batA, long long batB, long long batC, float alpha,
+                    void* stream) {
+  if (precision == 0)
+    return eovae_gemm_f32(A, B, Cm, batch, M, N, K, sam, sak, sbk, sbn, scm, scn, batA, batB, batC,
+                          alpha, stream);
+  return eovae_gemm_bf16x3(A, B, Cm, nullptr, nullptr, batch, M, N, K, sam, sak, sbk, sbn, scm, scn,
+                           batA, batB, batC, alpha, 1, 0, precision, stream);
+}
+
 // Fused-by-sequence attention forward: P (B x T x T, caller-allocated, kept for backward) and
 // O[b][c][t].  q, k, v, o: [B][C][T] contiguous.
 int eovae_attention_fwd(const float* q, const float* k, const float* v, float* p, float* o,
-                        int B, int Cc, int T, float scale, void* stream) {
+                        int B, int Cc, int T, float scale, int precision, void* stream) {
   long long ct = (long long)Cc * T, tt = (long long)T * T;
-  int rc = eovae_gemm_f32(q, k, p, B, T, T, Cc, 1, T, T, 1, T, 1, ct, ct, tt, scale, stream);
+  int rc = gemm_any(precision, q, k, p, B, T, T, Cc, 1, T, T, 1, T, 1, ct, ct, tt, scale, stream);
   if (rc) return rc;
   rc = eovae_softmax_rows(p, (long long)B * T, T, stream);
   if (rc) return rc;
   // O(m=c, n=i) = sum_j V(c,j) P(i,j)
-  return eovae_gemm_f32(v, p, o, B, Cc, T, T, T, 1, 1, T, T, 1, ct, tt, ct, 1.f, stream);
+  return gemm_any(precision, v, p, o, B, Cc, T, T, T, 1, 1, T, T, 1, ct, tt, ct, 1.f, stream);
 }
 
 // Backward: dq, dk, dv from do; dp is B x T x T scratch (overwritten with dS).
 int eovae_attention_bwd(const float* q, const float* k, const float* v, const float* p,
                         const float* d_o, float* dp, float* dq, float* dk, float* dv, int B, int Cc,
-                        int T, float scale, void* stream) {
+                        int T, float scale, int precision, void* stream) {
   long long ct = (long long)Cc * T, tt = (long long)T * T;
   // dV(m=c, n=j) = sum_i dO(c,i) P(i,j)
-  int rc = eovae_gemm_f32(d_o, p, dv, B, Cc, T, T, T, 1, T, 1, T, 1, ct, tt, ct, 1.f, stream);
+  int rc = gemm_any(precision, d_o, p, dv, B, Cc, T, T, T, 1, T, 1, T, 1, ct, tt, ct, 1.f, stream);
   if (rc) return rc;
   // dP(m=i, n=j) = sum_c dO(c,i) V(c,j)
-  rc = eovae_gemm_f32(d_o, v, dp, B, T, T, Cc, 1, T, T, 1, T, 1, ct, ct, tt, 1.f, stream);
+  rc = gemm_any(precision, d_o, v, dp, B, T, T, Cc, 1, T, T, 1, T, 1, ct, ct, tt, 1.f, stream);
   if (rc) return rc;
   rc = eovae_softmax_bwd_rows(p, dp, (long long)B * T, T, stream);
   if (rc) return rc;
   // dQ(m=c, n=i) = scale * sum_j K(c,j) dS(i,j)
-  rc = eovae_gemm_f32(k, dp, dq, B, Cc, T, T, T, 1, 1, T, T, 1, ct, tt, ct, scale, stream);
+  rc = gemm_any(precision, k, dp, dq, B, Cc, T, T, T, 1, 1, T, T, 1, ct, tt, ct, scale, stream);
   if (rc) return rc;
   // dK(m=c, n=j) = scale * sum_i Q(c,i) dS(i,j)
-  return eovae_gemm_f32(q, dp, dk, B, Cc, T, T, T, 1, T, 1, T, 1, ct, tt, ct, scale, stream);
+  return gemm_any(precision, q, dp, dk, B, Cc, T, T, T, 1, T, 1, T, 1, ct, tt, ct, scale, stream);
 }
 
 }  // extern "C"

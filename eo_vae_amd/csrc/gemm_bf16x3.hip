@@ -1,0 +1,218 @@
+// Strided-batched GEMM with split-bf16 operands on the bf16 matrix cores:
+//     C[b](m,n) (+)= alpha * sum_k A[b](m,k) * B[b](k,n)  (+ bias[m]) (+ res[b](m,n))
+// A and B are fp32 in global memory with arbitrary element strides (one unit stride each); they
+// are split to hi/lo bf16 while being staged into LDS as [k-step][row][16 k] images (32-byte
+// rows: an MFMA fragment is one aligned ds_read_b128, 32 rows = 1 KiB contiguous).
+// Serves every 1x1 convolution of the path (nin_shortcut, attention q/k/v/proj_out, quant convs:
+// layers.py:84-87,123-126; model.py:165,236) -- forward, data gradient and (atomic, batch-reduced)
+// weight gradient -- and the five attention contractions (layers.py:133-139).
+// 1x1 convolutions are L2/HBM-bandwidth bound at these channel counts (<= 64 flop/byte).
+#include "eovae_common.h"
+
+namespace {
+
+struct GemmBArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* res;
+  int M, N, K;
+  long long sam, sak, sbk, sbn, scm, scn;
+  long long batA, batB, batC;
+  float alpha;
+  int tiles_m, tiles_n, ksplit, atomic;
+};
+
+__device__ __forceinline__ void split8g(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+template <bool A_KC, bool B_KC, int NTERMS>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
+  constexpr int BM = 128, BN = 256, KS = 32;
+  constexpr int A_IMG = 2 * BM * 32, B_IMG = 2 * BN * 32;  // bytes of one (hi or lo) stage image
+  constexpr int OFF_ALO = A_IMG, OFF_B = 2 * A_IMG, OFF_BLO = 2 * A_IMG + B_IMG;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_IMG + 2 * B_IMG];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int tm = b % g.tiles_m;
+  b /= g.tiles_m;
+  const int tn = b % g.tiles_n;
+  b /= g.tiles_n;
+  const int ks_id = b % g.ksplit;
+  const int bat = b / g.ksplit;
+  const float* A = g.A + bat * g.batA;
+  const float* B = g.B + bat * g.batB;
+  float* C = g.C + bat * g.batC;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  // K range of this block (multiples of the 32-deep stage)
+  const int stages_total = (g.K + KS - 1) / KS;
+  const int per = (stages_total + g.ksplit - 1) / g.ksplit;
+  const int s_beg = ks_id * per;
+  int s_end = s_beg + per;
+  if (s_end > stages_total) s_end = stages_total;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  float ar[8], br[2][8];
+  // task -> (row, octet) maps chosen so the global loads coalesce along the contiguous axis
+  auto a_task = [&](int t, int& m, int& oct) {
+    if (A_KC) { m = t >> 2; oct = t & 3; } else { m = t & (BM - 1); oct = t >> 7; }
+  };
+  auto b_task = [&](int t, int& n, int& oct) {
+    if (B_KC) { n = t >> 2; oct = t & 3; } else { n = t & (BN - 1); oct = t >> 8; }
+  };
+  auto load_stage = [&](int s) {
+    const int k0 = s * KS;
+    {
+      int m, oct;
+      a_task(tid, m, oct);
+      const bool okm = m0 + m < g.M;
+      const float* p = A + (long long)(m0 + m) * g.sam + (long long)(k0 + oct * 8) * g.sak;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        ar[j] = (okm && k0 + oct * 8 + j < g.K) ? p[(long long)j * g.sak] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int n, oct;
+      b_task(tid + i * 512, n, oct);
+      const bool okn = n0 + n < g.N;
+      const float* p = B + (long long)(n0 + n) * g.sbn + (long long)(k0 + oct * 8) * g.sbk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        br[i][j] = (okn && k0 + oct * 8 + j < g.K) ? p[(long long)j * g.sbk] : 0.f;
+    }
+  };
+  auto store_stage = [&]() {
+    {
+      int m, oct;
+      a_task(tid, m, oct);
+      bf16x8 hi, lo;
+      split8g(ar, hi, lo);
+      const int off = (oct >> 1) * (BM * 32) + m * 32 + (oct & 1) * 16;
+      *reinterpret_cast<bf16x8*>(smem + off) = hi;
+      if (NTERMS == 3) *reinterpret_cast<bf16x8*>(smem + OFF_ALO + off) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int n, oct;
+      b_task(tid + i * 512, n, oct);
+      bf16x8 hi, lo;
+      split8g(br[i], hi, lo);
+      const int off = (oct >> 1) * (BN * 32) + n * 32 + (oct & 1) * 16;
+      *reinterpret_cast<bf16x8*>(smem + OFF_B + off) = hi;
+      if (NTERMS == 3) *reinterpret_cast<bf16x8*>(smem + OFF_BLO + off) = lo;
+    }
+  };
+
+  if (s_beg < s_end) load_stage(s_beg);
+  for (int s = s_beg; s < s_end; ++s) {
+    __syncthreads();
+    store_stage();
+    __syncthreads();
+    if (s + 1 < s_end) load_stage(s + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = kk * (BM * 32) + (wm + i * 32 + r) * 32 + h * 16;
+        ahi[i] = *reinterpret_cast<const bf16x8*>(smem + off);
+        if (NTERMS == 3) alo[i] = *reinterpret_cast<const bf16x8*>(smem + OFF_ALO + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = kk * (BN * 32) + (wn + j * 32 + r) * 32 + h * 16;
+        bhi[j] = *reinterpret_cast<const bf16x8*>(smem + OFF_B + off);
+        if (NTERMS == 3) blo[j] = *reinterpret_cast<const bf16x8*>(smem + OFF_BLO + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (NTERMS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (m >= g.M) continue;
+      const float bias = (g.bias && ks_id == 0) ? g.bias[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + j * 32 + r;
+        if (n >= g.N) continue;
+        const long long o = (long long)m * g.scm + (long long)n * g.scn;
+        float v = acc[i][j][q] * g.alpha + bias;
+        if (g.res && ks_id == 0) v += g.res[bat * g.batC + o];
+        if (g.atomic) atomicAdd(&C[o], v);
+        else C[o] = v;
+      }
+    }
+}
+
+template <int NT>
+void launch(const GemmBArgs& g, dim3 grid, hipStream_t st, bool ak, bool bk) {
+  if (ak && bk) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, NT>), grid, dim3(512), 0, st, g);
+  else if (ak) hipLaunchKernelGGL((gemm_bf16_kernel<true, false, NT>), grid, dim3(512), 0, st, g);
+  else if (bk) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, NT>), grid, dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, NT>), grid, dim3(512), 0, st, g);
+}
+
+}  // namespace
+
+extern "C" {
+
+// precision 3 = bf16x3, 1 = bf16.  atomic = 1: C += (caller pre-zeroes C; required when ksplit > 1
+// or when several batches share C through batC = 0).
+int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, const float* res,
+                      int batch, int M, int N, int K, long long sam, long long sak, long long sbk,
+                      long long sbn, long long scm, long long scn, long long batA, long long batB,
+                      long long batC, float alpha, int ksplit, int atomic, int precision,
+                      void* stream) {
+  EOVAE_CHECK_ARG(A && B && C, "gemm_bf16x3: null pointer");
+  EOVAE_CHECK_ARG(batch > 0 && M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape");
+  EOVAE_CHECK_ARG(sam == 1 || sak == 1, "gemm_bf16x3: A needs a unit stride");
+  EOVAE_CHECK_ARG(sbk == 1 || sbn == 1, "gemm_bf16x3: B needs a unit stride");
+  EOVAE_CHECK_ARG(precision == 1 || precision == 3, "gemm_bf16x3: precision %d", precision);
+  EOVAE_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || atomic), "gemm_bf16x3: ksplit > 1 needs atomic");
+  EOVAE_CHECK_ARG(batC != 0 || batch == 1 || atomic, "gemm_bf16x3: shared C needs atomic");
+  GemmBArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = res;
+  g.M = M; g.N = N; g.K = K;
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.scm = scm; g.scn = scn;
+  g.batA = batA; g.batB = batB; g.batC = batC; g.alpha = alpha;
+  g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 256); g.ksplit = ksplit; g.atomic = atomic;
+  dim3 grid((unsigned)(batch * ksplit * g.tiles_m * g.tiles_n));
+  const bool ak = (sak == 1 && sam != 1), bk = (sbk == 1 && sbn != 1);
+  if (precision == 3) launch<3>(g, grid, (hipStream_t)stream, ak, bk);
+  else launch<1>(g, grid, (hipStream_t)stream, ak, bk);
+  EOVAE_CHECK_LAUNCH("eovae_gemm_bf16x3");
+  return EOVAE_OK;
+}
+
+}  // extern "C"

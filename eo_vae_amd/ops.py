@@ -132,6 +132,44 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
     return y
 
 
+def _gemm_prec():
+    return 0 if CONV_PRECISION == 'f32' else _PREC[CONV_PRECISION]
+
+
+def conv1x1_lowp(x, weight, bias, residual):
+    """y[n] = W x[n] (+bias, +residual) as a batched split-bf16 GEMM."""
+    n, cin, h, w = x.shape
+    cout, hw = weight.shape[0], h * w
+    y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.load().eovae_gemm_bf16x3(L.ptr(weight), L.ptr(x), L.ptr(y), L.ptr(bias), L.ptr(residual), n,
+                                       cout, hw, cin, cin, 1, hw, 1, hw, 1, 0, cin * hw, cout * hw, 1.0, 1,
+                                       0, _PREC[CONV_PRECISION], L.stream()), 'eovae_gemm_bf16x3')
+    return y
+
+
+def conv1x1_lowp_dgrad(dy, weight):
+    n, cout, h, w = dy.shape
+    cin, hw = weight.shape[1], h * w
+    dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
+    L.check(L.load().eovae_gemm_bf16x3(L.ptr(weight), L.ptr(dy), L.ptr(dx), None, None, n, cin, hw, cout,
+                                       1, cin, hw, 1, hw, 1, 0, cout * hw, cin * hw, 1.0, 1, 0,
+                                       _PREC[CONV_PRECISION], L.stream()), 'eovae_gemm_bf16x3')
+    return dx
+
+
+def conv1x1_lowp_wgrad(x, dy):
+    """dW[co][ci] = sum_n sum_p dy[n][co][p] x[n][ci][p]: batch- and K-split blocks add atomically."""
+    n, cin, h, w = x.shape
+    cout, hw = dy.shape[1], h * w
+    dw = torch.zeros(cout, cin, 1, 1, dtype=torch.float32, device=x.device)
+    tiles = ((cout + 127) // 128) * ((cin + 255) // 256)
+    ksplit = max(1, min(512 // max(1, tiles * n), max(1, hw // 64)))
+    L.check(L.load().eovae_gemm_bf16x3(L.ptr(dy), L.ptr(x), L.ptr(dw), None, None, n, cout, cin, hw, hw, 1,
+                                       1, hw, cin, 1, cout * hw, cin * hw, 0, 1.0, ksplit, 1,
+                                       _PREC[CONV_PRECISION], L.stream()), 'eovae_gemm_bf16x3')
+    return dw
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv(x, w) + b (+ residual); mode in {'normal','down','up'} (see csrc/conv_f32.hip)."""
 
@@ -147,6 +185,8 @@ class Conv2dFn(torch.autograd.Function):
         bias_c = _c(bias) if bias is not None else None
         if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
             y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False)
+        elif ks == 1 and CONV_PRECISION != 'f32':
+            y = conv1x1_lowp(x, weight, bias_c, res)
         else:
             wp, kp, mp = pack_weights(weight, m, False)
             y = conv_raw(x, wp, kp, mp, bias_c, res, cout, ks, m)
@@ -175,6 +215,8 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 L.check(lib.eovae_upsample2x_bwd(L.ptr(du), L.ptr(dx), n, cin, h, w, L.stream()),
                         'eovae_upsample2x_bwd')
+        elif ctx.needs_input_grad[0] and ks == 1 and CONV_PRECISION != 'f32':
+            dx = conv1x1_lowp_dgrad(dy, weight)
         elif ctx.needs_input_grad[0]:
             wp, kp, mp = pack_weights(weight, m, True)
             if m == MODE_NORMAL:
@@ -188,7 +230,9 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 L.check(lib.eovae_upsample2x_bwd(L.ptr(du), L.ptr(dx), n, cin, h, w, L.stream()),
                         'eovae_upsample2x_bwd')
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
+            dw = conv1x1_lowp_wgrad(x, dy)
+        elif ctx.needs_input_grad[1]:
             dwp = torch.zeros(ks * ks * cout * cin, dtype=torch.float32, device=x.device)
             if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
                 L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
@@ -269,7 +313,7 @@ class AttentionFn(torch.autograd.Function):
         p = torch.empty(b, t, t, dtype=torch.float32, device=q.device)
         o = torch.empty_like(q)
         L.check(L.load().eovae_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(p), L.ptr(o), b, c, t,
-                                             scale, L.stream()), 'eovae_attention_fwd')
+                                             scale, _gemm_prec(), L.stream()), 'eovae_attention_fwd')
         ctx.save_for_backward(q, k, v, p)
         ctx.scale = scale
         return o
@@ -283,7 +327,7 @@ class AttentionFn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         L.check(L.load().eovae_attention_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(p), L.ptr(do),
                                              L.ptr(dp), L.ptr(dq), L.ptr(dk), L.ptr(dv), b, c, t,
-                                             ctx.scale, L.stream()), 'eovae_attention_bwd')
+                                             ctx.scale, _gemm_prec(), L.stream()), 'eovae_attention_bwd')
         return dq, dk, dv, None
 
 

@@ -115,11 +115,22 @@ LOWP_CASES = [(2, 32, 32, 16, 16, 'normal'), (1, 128, 128, 64, 64, 'normal'), (2
 @pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
 @pytest.mark.parametrize('n,cin,cout,h,w,mode', LOWP_CASES)
 def test_conv3x3_split_bf16(n, cin, cout, h, w, mode, precision, tol):
+    _lowp_case(n, cin, cout, h, w, 3, mode, precision, tol)
+
+
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 192, 16, 16), (4, 512, 512, 32, 32), (2, 32, 32, 8, 8),
+                                            (1, 256, 128, 40, 24), (3, 64, 64, 9, 7)])
+def test_conv1x1_split_bf16(n, cin, cout, h, w, precision, tol):
+    _lowp_case(n, cin, cout, h, w, 1, 'normal', precision, tol)
+
+
+def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol):
     """bf16x3 (hi*hi + hi*lo + lo*hi on the bf16 MFMA) must be fp32-grade: ~2^-17 per product;
     plain bf16 is the flagged fast mode (2^-9) and only has to be sane."""
     from eo_vae_amd import ops
     x = hashed((n, cin, h, w), 1, 1.0)
-    wt = hashed((cout, cin, 3, 3), 2, 1.0 / (cin * 9) ** 0.5)
+    wt = hashed((cout, cin, ks, ks), 2, 1.0 / (cin * ks * ks) ** 0.5)
     b = hashed((cout,), 3, 0.1)
     xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yr = ref_conv(xr, wr, br, mode)
