@@ -10,14 +10,16 @@
 // Same GEMM view and tile-loader index map (normal / nearest-x2 / zero-insert) as conv_f32.hip:
 //   D[co][pix] = sum_tap sum_ci Wp[tap][ci][co] * Xv[ci][pix @ tap]
 // Block = 512 threads = 8 waves, tile 128 co x (TH x 32) pixels, K streamed in 16-channel chunks.
-//   * X halo tile: fp32 NCHW -> registers -> split -> LDS as [pixel][16 ci] bf16 (hi and lo
-//     images).  A lane's MFMA B fragment (8 consecutive ci of one pixel) is ONE 16-byte
-//     ds_read_b128; 32 consecutive pixels of a row are 1 KiB contiguous => conflict-free, and a
-//     tap shift moves whole pixels, so every read stays 16-byte aligned.
-//   * W tile: pre-split, pre-tiled in global as [tap][chunk][co-block][hi|lo][128 co][16 ci];
+//   * X halo tile: fp32 NCHW -> registers -> split -> LDS as [k-half][pixel][8 ci] bf16 (hi and
+//     lo images).  A lane's MFMA B fragment (8 consecutive ci of one pixel) is ONE 16-byte
+//     ds_read_b128; the 32 lanes of a k-half read 32 consecutive pixels = 512 contiguous bytes
+//     => bank-conflict free (a [pixel][16 ci] image with 32-byte rows measured 46 % conflict
+//     cycles), and a tap shift moves whole pixels, so every read stays 16-byte aligned.
+//   * W tile: pre-split, pre-tiled in global as [tap][chunk][co-block][hi|lo][k-half][128 co][8 ci];
 //     staged per ky-row phase (3 taps, 24 KiB) by straight 16-byte copies, double buffered.
 //   * per chunk: 3 phases x 3 taps x (2 x NI tiles) x NTERMS MFMAs per wave.
 #include "eovae_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
         const int g = t / NPX, pix = t - g * NPX;
         bf16x8 hi, lo;
         split8(xr[i], hi, lo);
-        *reinterpret_cast<bf16x8*>(smem + pix * 32 + g * 16) = hi;
-        if (NTERMS == 3) *reinterpret_cast<bf16x8*>(smem + OFF_XLO + pix * 32 + g * 16) = lo;
+        *reinterpret_cast<bf16x8*>(smem + g * (NPX * 16) + pix * 16) = hi;
+        if (NTERMS == 3) *reinterpret_cast<bf16x8*>(smem + OFF_XLO + g * (NPX * 16) + pix * 16) = lo;
       }
     }
   };
@@ -164,16 +166,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
       bf16x8 ahi[2], alo[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int off = kx * WTAP + ((wco + i * 32 + r) * KC + 8 * h) * 2;
+        const int off = kx * WTAP + h * (BM * 16) + (wco + i * 32 + r) * 16;
         ahi[i] = *reinterpret_cast<const bf16x8*>(wb + off);
         if (NTERMS == 3) alo[i] = *reinterpret_cast<const bf16x8*>(wb + off + BM * KC * 2);
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int pix = (wrow + j + ky) * XW + r + kx;
-        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(smem + pix * 32 + h * 16);
+        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(smem + h * (NPX * 16) + pix * 16);
         bf16x8 blo;
-        if (NTERMS == 3) blo = *reinterpret_cast<const bf16x8*>(smem + OFF_XLO + pix * 32 + h * 16);
+        if (NTERMS == 3)
+          blo = *reinterpret_cast<const bf16x8*>(smem + OFF_XLO + h * (NPX * 16) + pix * 16);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (NTERMS == 3) {
@@ -224,17 +227,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 // would break the 16-byte alignment of a K-contiguous fragment read.  So both tiles are staged
 // channel-contiguous ([pixel][32 channels], 64-byte rows: a tap shift moves whole rows) and the
 // fragments are gathered with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group,
-// delivered pixel-major per lane); 4 consecutive pixel rows = 256 contiguous bytes => no bank
-// conflicts.  Pixel tiles of 2 x 32 are double buffered in LDS; the next tile is loaded one
-// k-step (16 pixels) at a time behind the current k-step's 27 MFMAs.
+// delivered pixel-major per lane); 4 consecutive pixel rows = 256 contiguous bytes => no read
+// conflicts.  The staging WRITES put 16 consecutive pixels (64-byte stride) of one channel group
+// in one instruction, 4-8-way conflicted on a plain image (45 % conflict cycles measured), so the
+// 8-byte (dY) / 16-byte (X) channel groups of row p are XOR-swizzled by (p>>1): writes become
+// conflict free and a row stays a permutation of itself, so reads stay conflict free too; the
+// swizzled per-lane read offsets are loop-invariant registers.  Pixel tiles of 2 x 32 are double
+// buffered in LDS; the next tile is loaded one k-step (16 pixels) at a time behind the current
+// k-step's 27 MFMAs.
 // ---------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
   using lds4 = __attribute__((address_space(3))) s16x4;
-  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p));
-  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p + 4 * 64));
+  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p0));
+  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p1));
   const s16x8 f = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, f);
 }
@@ -250,7 +258,8 @@ struct WgBArgs {
 
 template <int NTERMS>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
-  constexpr int PW = 32, XW = 34, NXP = 4 * XW;          // 2 output rows + halo
+  constexpr int PW = 32, XW = 40, XWV = 34, NXP = 4 * XW;  // 2 output rows + halo; LDS row pitch 40
+                                                          // pixels (34 valid) keeps every window start = kx (mod 8)
   constexpr int DPART = 4 * 64 * 64;                      // [4 co-tiles][64 pix][32 co] bf16
   constexpr int XPART = 2 * NXP * 64;                     // [2 ci-tiles][136 pix][32 ci] bf16
   constexpr int OFF_X = 2 * DPART;
@@ -264,8 +273,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   const int ct = wave & 3, cih = wave >> 2;
   const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
   const size_t in_plane = (size_t)a.Hin * a.Win, out_plane = (size_t)a.Hout * a.Wout;
-  // per-lane byte offset inside a [pixel][32 ch] image for a transposed 4x16 block read
-  const int tr_lane = (8 * (g >> 1) + lq) * 64 + (16 * (g & 1) + 4 * lp) * 2;
+  // per-lane byte offsets inside a swizzled [pixel][32 ch] image for the two transposed 4x16 block
+  // reads of a fragment (pixel rows lpart and lpart+4 of the 16-pixel k-step, 8-byte chunk lchunk)
+  const int lpart = 8 * (g >> 1) + lq, lchunk = 4 * (g & 1) + lp;
+  // dY image: chunk ^ ((row>>1)&7); row = 16*ks + lpart(+4) and 16*ks never reaches those bits
+  const int sa0 = lpart * 64 + ((lchunk ^ ((lpart >> 1) & 7)) * 8);
+  const int sa1 = (lpart + 4) * 64 + ((lchunk ^ (((lpart + 4) >> 1) & 7)) * 8);
+  // X image: 16-byte unit ^ ((pix>>1)&3); pix = base + lpart(+4), so one offset per (base & 7)
+  int sx[8];
+#pragma unroll
+  for (int res = 0; res < 8; ++res)
+    sx[res] = lpart * 64 + (((lchunk >> 1) ^ (((res + lpart) >> 1) & 3)) * 16) + (lchunk & 1) * 8;
 
   f32x16 acc[9];
 #pragma unroll
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       const int t2 = ks * XQ + tid;
       const int oct = t2 / NXP, pix = t2 - oct * NXP;
       const int rr = pix / XW, cc = pix - rr * XW;
-      const int si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+      const int si = cc < XWV ? src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win) : -1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ci = cib * 64 + oct * 8 + j;
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
         hi[j] = hb;
         lo[j] = (__bf16)(dq[j] - (float)hb);
       }
-      const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (quad & 7) * 8;
+      const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
       *reinterpret_cast<bf16x4v*>(base + off) = hi;
       if (NTERMS == 3) *reinterpret_cast<bf16x4v*>(base + DPART + off) = lo;
     }
@@ -329,32 +347,32 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       const int oct = t2 / NXP, pix = t2 - oct * NXP;
       bf16x8 hi, lo;
       split8(xq, hi, lo);
-      const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (oct & 3) * 16;
+      const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
       *reinterpret_cast<bf16x8*>(base + off) = hi;
       if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + XPART + off) = lo;
     }
   };
   auto compute = [&](const unsigned char* base, int ks) {
     const int row = ks >> 1, x0 = 16 * (ks & 1);
-    const unsigned char* ap = base + ct * 4096 + ks * 16 * 64 + tr_lane;
-    const bf16x8 ahi = tr_frag(ap);
+    const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
+    const bf16x8 ahi = tr_frag(ap + sa0, ap + sa1);
     bf16x8 alo;
-    if (NTERMS == 3) alo = tr_frag(ap + DPART);
+    if (NTERMS == 3) alo = tr_frag(ap + DPART + sa0, ap + DPART + sa1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap % 3;
-      const unsigned char* bp =
-          base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64 + tr_lane;
-      const bf16x8 bhi = tr_frag(bp);
+      // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8) -> static table index
+      const unsigned char* bp = base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64;
+      const int o0 = sx[kx], o1 = sx[kx + 4] + 4 * 64;
+      const bf16x8 bhi = tr_frag(bp + o0, bp + o1);
       if (NTERMS == 3) {
-        const bf16x8 blo = tr_frag(bp + XPART);
+        const bf16x8 blo = tr_frag(bp + XPART + o0, bp + XPART + o1);
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[tap], 0, 0, 0);
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[tap], 0, 0, 0);
       }
       acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[tap], 0, 0, 0);
     }
   };
-
   int tile = blockIdx.y;
   if (tile < a.ntiles) {
 #pragma unroll 1
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   }
 }
 
-// w[Cout][Cin][9] fp32 -> [tap][chunk][cob][hi|lo][128][16] bf16 bits (zero padded)
+// w[Cout][Cin][9] fp32 -> [tap][chunk][cob][hi|lo][k-half][128][8] bf16 bits (zero padded)
 //   flip = 0: k = ci, m = co;  flip = 1 (data gradient): k = co, m = ci, taps reversed
 __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
                                   int Cout, int Cin, int nchunk, int ncob, int flip, float scale) {
@@ -415,8 +433,9 @@ __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* _
     const __bf16 hb = (__bf16)v;
     const __bf16 lb = (__bf16)(v - (float)hb);
     const size_t tile = ((size_t)(tap * nchunk + chunk) * ncob + cob) * (2 * 128 * 16);
-    wp[tile + min_ * 16 + kin] = __builtin_bit_cast(unsigned short, hb);
-    wp[tile + 128 * 16 + min_ * 16 + kin] = __builtin_bit_cast(unsigned short, lb);
+    const size_t e = (size_t)(kin >> 3) * (128 * 8) + min_ * 8 + (kin & 7);
+    wp[tile + e] = __builtin_bit_cast(unsigned short, hb);
+    wp[tile + 128 * 16 + e] = __builtin_bit_cast(unsigned short, lb);
   }
 }
 
