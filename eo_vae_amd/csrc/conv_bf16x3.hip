@@ -93,17 +93,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   float xr[XPT][8];
   f32x4 wr[3];
 
+  // chunk-invariant source offsets of this thread's halo tasks (index math hoisted out of the
+  // K loop: it cost ~10 % of the kernel when recomputed per chunk)
+  int xsi[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int t = tid + i * 512;
+    const int g = t / NPX, pix = t - g * NPX;
+    const int rr = pix / XW, cc = pix - rr * XW;
+    const int si = (t < XTASKS) ? src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win) : -1;
+    // fold the octet's first channel in: offset of channel (g*8) at the source pixel, or -1
+    xsi[i] = si;
+  }
   auto load_x = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int t = tid + i * 512;
-      const int g = t / NPX, pix = t - g * NPX;
-      const int rr = pix / XW, cc = pix - rr * XW;
-      const int si = (t < XTASKS) ? src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win) : -1;
+      const int g = (tid + i * 512) / NPX;
+      const int si = xsi[i];
+      const float* src = xn + (size_t)(c0 + g * 8) * in_plane + (si >= 0 ? si : 0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ci = c0 + g * 8 + j;
-        xr[i][j] = (si >= 0 && ci < a.Cin) ? xn[(size_t)ci * in_plane + si] : 0.f;
+        xr[i][j] = (si >= 0 && ci < a.Cin) ? src[(size_t)j * in_plane] : 0.f;
       }
     }
   };
@@ -153,12 +164,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   store_w(0);
   __syncthreads();
 
+#ifndef EOVAE_ABL
+#define EOVAE_ABL 0
+#endif
   const int nphase = a.nchunk * 3;
   for (int p = 0; p < nphase; ++p) {
     const int chunk = p / 3, ky = p - chunk * 3;
     const int buf = p & 1;
-    if (p + 1 < nphase) load_w((p + 1) / 3, (p + 1) % 3);
-    if (ky == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
+    if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) load_w((p + 1) / 3, (p + 1) % 3);
+    if (!(EOVAE_ABL & 2)) if (ky == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
 
     const unsigned char* wb = smem + OFF_W + buf * WPHASE;
 #pragma unroll
@@ -188,12 +202,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
       }
     }
 
-    if (p + 1 < nphase) store_w(buf ^ 1);  // other buffer: last read in phase p-1, fenced below
+    if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) store_w(buf ^ 1);  // other buffer: last read in phase p-1, fenced below
     if (ky == 2 && chunk + 1 < a.nchunk) {
-      __syncthreads();  // every wave has finished reading this chunk's halo tile
-      store_x();
+      if (!(EOVAE_ABL & 4)) __syncthreads();  // every wave has finished reading this chunk's halo tile
+      if (!(EOVAE_ABL & 2)) store_x();
     }
-    __syncthreads();
+    if (!(EOVAE_ABL & 4)) __syncthreads();
   }
 
   const size_t out_plane = (size_t)a.Hout * a.Wout;

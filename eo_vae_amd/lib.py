@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeovae_hip.so')
+LIB_PATH = os.environ.get('EOVAE_LIB') or os.path.join(_HERE, 'libeovae_hip.so')
 
 _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ip = C.POINTER(C.c_int)
