@@ -155,6 +155,12 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         ips = args.batch * world * args.steps / elapsed
         k_ms, k_flops, k_n = timer.totals()
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
+            with open(os.path.join(ROOT, 'profiles', 'r01d_pmc_hbm_traffic.json')) as f:
+                traffic = json.load(f)['kernels']['conv3x3_bf16_kernel']['traffic_bytes_per_launch_corrected']
+        except Exception:
+            pass
         achieved = k_flops / (k_ms * 1e-3) if k_ms > 0 else 0.0
         r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / args.batch)  # img/s per GPU at the HBM roof
         f_img = F_STEP_PER_IMG.get(C, 2.69e12)
@@ -182,7 +188,9 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': round(achieved / 1e12, 2), 'peak': peak / 1e12,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'traffic': None, 'launches': k_n,
+                         'traffic': traffic if prec != 'f32' else None,
+                         'algorithmic_bytes_per_launch': round(timer.bytes_total() / max(k_n, 1)),
+                         'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
             'step_flops_tflops': round(f_img * ips / world / 1e12, 2),
             'hbm_roofline_frac': round(ips / world / r_hbm, 4),

@@ -67,10 +67,14 @@ class KernelTimer:
     def __init__(self):
         self.records = []  # (start_event, end_event, algorithmic_flops)
 
-    def bracket(self, flops):
+    def bracket(self, flops, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.append((a, b, flops))
+        self.nbytes = getattr(self, 'nbytes', 0.0) + nbytes
         return a, b
+
+    def bytes_total(self):
+        return getattr(self, 'nbytes', 0.0)
 
     def totals(self):
         torch.cuda.synchronize()
@@ -90,7 +94,7 @@ def conv_raw(x, wp, kp, mp, bias, residual, cout, ks, mode, out_scale=1.0):
         # algorithmic flops of the layer this launch implements (MODE_ZINS = adjoint of the
         # stride-2 layer: its algorithmic work is the stride-2 layer's, a quarter of the tile work)
         pix = (ho * wo) // 4 if mode == MODE_ZINS else ho * wo
-        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout * cin * 9)
+        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout * cin * 9, 4.0 * (x.numel() + y.numel()))
         ev0.record()
     L.check(L.load().eovae_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
                                       n, cin, h, w, cout, ho, wo, ks, mode, kp, mp, out_scale,
@@ -122,7 +126,8 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
     timed = CONV3X3_TIMER is not None
     if timed:
         pix = (ho * wo) // 4 if mode == MODE_ZINS else ho * wo
-        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout_gemm * cin_g * 9)
+        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout_gemm * cin_g * 9,
+                                         4.0 * (x.numel() + y.numel() + weight.numel()))
         ev0.record()
     L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
                                        cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION],
