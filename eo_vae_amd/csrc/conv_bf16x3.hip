@@ -261,6 +261,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
   return __builtin_bit_cast(bf16x8, f);
 }
 
+#ifndef EOVAE_WGRAD_BLOCKS
+#define EOVAE_WGRAD_BLOCKS 256
+#endif
+
 struct WgBArgs {
   const float* x;
   const float* dy;
@@ -529,7 +533,9 @@ int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N,
   a.ntiles = N * a.tiles_x * a.tiles_y;
   a.ncib = cdiv(Cin, 64);
   const int ncob = cdiv(Cout, 128);
-  int split = 512 / (a.ncib * ncob);
+  // one block per CU: every block ends with 1152 atomic wave-instructions (~58 us at the chip's
+  // ~50 ns per instruction per CU), so a second round of blocks would pay that tail twice
+  int split = EOVAE_WGRAD_BLOCKS / (a.ncib * ncob);
   if (split < 1) split = 1;
   if (split > a.ntiles) split = a.ntiles;
   dim3 grid(a.ncib * ncob, split);
