@@ -35,6 +35,12 @@ struct ConvBArgs {
   int nchunk, ncob;
   int mode;
   int tiles_x, tiles_y;
+  // sub-pixel form of "nearest x2 + 3x3" (4 parity kernels with 2x2 support, 4/9 of the MFMAs):
+  //   subpix 1 (forward):  M = 4*creal output channels (parity-major), x = low-res input,
+  //                        epilogue pixel-shuffles into y[N][creal][2H][2W]
+  //   subpix 2 (data grad): K = 4*creal channels (parity-major) gathered from the high-res dy,
+  //                        output = low-res dx; active taps depend on the chunk's parity
+  int subpix, creal, cpb;
 };
 
 __device__ __forceinline__ int src_index3(int mode, int oy0, int ox0, int r, int c, int Hin, int Win) {
@@ -88,7 +94,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int wco = (wave & 1) * 64, wrow = (wave >> 1) * NI;
   const size_t in_plane = (size_t)a.Hin * a.Win;
-  const float* xn = a.x + (size_t)n * a.Cin * in_plane;
+  const int xch = a.subpix == 2 ? a.creal : a.Cin;  // channels of the stored input tensor
+  const float* xn = a.x + (size_t)n * xch * in_plane;
+  // active tap window [ky0, ky0+kyn) x [kx0, kx0+kxn): all 9 taps, or the 2x2 support of a parity
+  const int kyn = a.subpix ? 2 : 3, kxn = kyn;
+  const int par1 = a.subpix == 1 ? cob / a.cpb : 0;  // forward: parity of this block's output rows
+  auto parity_of = [&](int chunk) { return a.subpix == 2 ? (chunk * KC) / a.creal : par1; };
+  auto ky0_of = [&](int par) { return a.subpix == 1 ? (par >> 1) : (a.subpix == 2 ? 1 - (par >> 1) : 0); };
+  auto kx0_of = [&](int par) { return a.subpix == 1 ? (par & 1) : (a.subpix == 2 ? 1 - (par & 1) : 0); };
 
   float xr[XPT][8];
   f32x4 wr[3];
@@ -101,16 +114,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
     const int t = tid + i * 512;
     const int g = t / NPX, pix = t - g * NPX;
     const int rr = pix / XW, cc = pix - rr * XW;
-    const int si = (t < XTASKS) ? src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win) : -1;
-    // fold the octet's first channel in: offset of channel (g*8) at the source pixel, or -1
+    int si = -1;
+    if (t < XTASKS) {
+      if (a.subpix == 2) {  // low-res halo pixel (vy, vx) -> index of high-res pixel (2vy, 2vx)
+        const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
+        if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout) si = 2 * vy * a.Win + 2 * vx;
+      } else {
+        si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+      }
+    }
     xsi[i] = si;
   }
   auto load_x = [&](int c0) {
+    int cbase = c0, poff = 0;
+    if (a.subpix == 2) {  // channel chunk of parity p reads dy[co][2vy+py][2vx+px]
+      const int par = c0 / a.creal;
+      cbase = c0 - par * a.creal;
+      poff = (par >> 1) * a.Win + (par & 1);
+    }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int g = (tid + i * 512) / NPX;
       const int si = xsi[i];
-      const float* src = xn + (size_t)(c0 + g * 8) * in_plane + (si >= 0 ? si : 0);
+      const float* src = xn + (size_t)(cbase + g * 8) * in_plane + (si >= 0 ? si + poff : 0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ci = c0 + g * 8 + j;
@@ -159,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   load_x(0);
-  load_w(0, 0);
+  load_w(0, ky0_of(parity_of(0)));
   store_x();
   store_w(0);
   __syncthreads();
@@ -167,16 +193,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 #ifndef EOVAE_ABL
 #define EOVAE_ABL 0
 #endif
-  const int nphase = a.nchunk * 3;
+  // phase p = (chunk, active tap row): one row of taps of one 16-channel chunk
+  const int nphase = a.nchunk * kyn;
   for (int p = 0; p < nphase; ++p) {
-    const int chunk = p / 3, ky = p - chunk * 3;
+    const int chunk = p / kyn, kyi = p - chunk * kyn;
+    const int par = parity_of(chunk);
+    const int ky = ky0_of(par) + kyi, kx0 = kx0_of(par);
     const int buf = p & 1;
-    if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) load_w((p + 1) / 3, (p + 1) % 3);
-    if (!(EOVAE_ABL & 2)) if (ky == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
+    if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) {
+      const int nchk = (p + 1) / kyn;
+      load_w(nchk, ky0_of(parity_of(nchk)) + (p + 1 - nchk * kyn));
+    }
+    if (!(EOVAE_ABL & 2)) if (kyi == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
 
     const unsigned char* wb = smem + OFF_W + buf * WPHASE;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
+      if (kx < kx0 || kx >= kx0 + kxn) continue;  // uniform: taps outside the parity's 2x2 support
       bf16x8 ahi[2], alo[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -203,13 +236,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
     }
 
     if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) store_w(buf ^ 1);  // other buffer: last read in phase p-1, fenced below
-    if (ky == 2 && chunk + 1 < a.nchunk) {
+    if (kyi == kyn - 1 && chunk + 1 < a.nchunk) {
       if (!(EOVAE_ABL & 4)) __syncthreads();  // every wave has finished reading this chunk's halo tile
       if (!(EOVAE_ABL & 2)) store_x();
     }
     if (!(EOVAE_ABL & 4)) __syncthreads();
   }
 
+  if (a.subpix == 1) {  // pixel-shuffle store: parity (py,px) block -> y[n][co][2*oy+py][2*ox+px]
+    const int py = par1 >> 1, px = par1 & 1;
+    const size_t out_plane = (size_t)a.Hout * a.Wout * 4;
+    const int ox = ox0 + r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = (cob - par1 * a.cpb) * BM + wco + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (co >= a.creal) continue;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int oy = oy0 + wrow + j;
+          if (oy < a.Hout && ox < a.Wout) {
+            const size_t o = ((size_t)n * a.creal + co) * out_plane +
+                             (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px;
+            a.y[o] = acc[i][j][q] + bias;
+          }
+        }
+      }
+    }
+    return;
+  }
   const size_t out_plane = (size_t)a.Hout * a.Wout;
   const int ox = ox0 + r;
 #pragma unroll
@@ -272,10 +329,14 @@ struct WgBArgs {
   int N, Cin, Hin, Win, Cout, Hout, Wout;
   int mode;
   int tiles_x, tiles_y, ntiles, ncib;
+  // subpix 1: rows are the 4*creal parity-major output channels of the sub-pixel form; dy is the
+  // high-res gradient gathered at the block's parity; only the parity's 2x2 taps are accumulated
+  int subpix, creal, cpb;
 };
 
-template <int NTERMS>
+template <int NTERMS, bool SUBPIX>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
+  constexpr int NT = SUBPIX ? 4 : 9;  // accumulated taps: all 9, or the parity's 2x2 support
   constexpr int PW = 32, XW = 40, XWV = 34, NXP = 4 * XW;  // 2 output rows + halo; LDS row pitch 40
                                                           // pixels (34 valid) keeps every window start = kx (mod 8)
   constexpr int DPART = 4 * 64 * 64;                      // [4 co-tiles][64 pix][32 co] bf16
@@ -290,7 +351,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
   const int ct = wave & 3, cih = wave >> 2;
   const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
-  const size_t in_plane = (size_t)a.Hin * a.Win, out_plane = (size_t)a.Hout * a.Wout;
+  const int par = SUBPIX ? cob / a.cpb : 0, py = par >> 1, px = par & 1;
+  const int dych = SUBPIX ? a.creal : a.Cout;   // channels / plane of the stored dy tensor
+  const size_t in_plane = (size_t)a.Hin * a.Win;
+  const size_t out_plane = SUBPIX ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
   // per-lane byte offsets inside a swizzled [pixel][32 ch] image for the two transposed 4x16 block
   // reads of a fragment (pixel rows lpart and lpart+4 of the 16-pixel k-step, 8-byte chunk lchunk)
   const int lpart = 8 * (g >> 1) + lq, lchunk = 4 * (g & 1) + lp;
@@ -298,14 +362,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   const int sa0 = lpart * 64 + ((lchunk ^ ((lpart >> 1) & 7)) * 8);
   const int sa1 = (lpart + 4) * 64 + ((lchunk ^ (((lpart + 4) >> 1) & 7)) * 8);
   // X image: 16-byte unit ^ ((pix>>1)&3); pix = base + lpart(+4), so one offset per (base & 7)
-  int sx[8];
-#pragma unroll
-  for (int res = 0; res < 8; ++res)
-    sx[res] = lpart * 64 + (((lchunk >> 1) ^ (((res + lpart) >> 1) & 3)) * 16) + (lchunk & 1) * 8;
+  auto sx_of = [&](int res) {
+    return lpart * 64 + (((lchunk >> 1) ^ (((res + lpart) >> 1) & 3)) * 16) + (lchunk & 1) * 8;
+  };
+  // window start = kx (mod 8): named scalars, never an indexable array (that would go to scratch)
+  const int sx0 = sx_of(0), sx1 = sx_of(1), sx2 = sx_of(2), sx4 = sx_of(4), sx5 = sx_of(5), sx6 = sx_of(6);
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
@@ -313,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   // the other LDS buffer after them.  dY is staged by ALL 512 threads (4 channels x 1 pixel
   // each), the X halo by the first 272 (8 channels x 1 pixel).
   float dyr[1][4], xr[1][8];
-  auto issue = [&](int tile, int ks, float (&dq)[4], float (&xq)[8]) {
+  auto issue = [&](int tile, int ks, float (&dq)[4], float (&xq)[8]) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
@@ -324,12 +389,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels
       const int oy = oy0 + (ks >> 1), ox = ox0 + 16 * (ks & 1) + pixl;
       const bool ok = oy < a.Hout && ox < a.Wout;
+      const size_t pixoff = SUBPIX ? (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px
+                                   : (size_t)oy * a.Wout + ox;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int co = cob * 128 + quad * 4 + j;
-        dq[j] = (ok && co < a.Cout)
-                    ? a.dy[((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wout + ox]
-                    : 0.f;
+        dq[j] = (ok && co < a.Cout) ? a.dy[((size_t)n * dych + (co - (SUBPIX ? par * a.creal : 0))) * out_plane + pixoff]
+                                    : 0.f;
       }
     }
     if (tid < XQ) {
@@ -344,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       }
     }
   };
-  auto commit = [&](int buf, int ks, const float (&dq)[4], const float (&xq)[8]) {
+  auto commit = [&](int buf, int ks, const float (&dq)[4], const float (&xq)[8]) __attribute__((always_inline)) {
     unsigned char* base = smem + buf * BUF;
     {
       const int pixl = tid & 15, quad = tid >> 4;
@@ -370,27 +436,40 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + XPART + off) = lo;
     }
   };
-  auto compute = [&](const unsigned char* base, int ks) {
+  // PARC = compile-time parity (sub-pixel form) so every tap index / swizzle offset is static
+  auto compute_p = [&](const unsigned char* base, int ks, auto parc) __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
     const int row = ks >> 1, x0 = 16 * (ks & 1);
     const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
     const bf16x8 ahi = tr_frag(ap + sa0, ap + sa1);
     bf16x8 alo;
     if (NTERMS == 3) alo = tr_frag(ap + DPART + sa0, ap + DPART + sa1);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
-      // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8) -> static table index
+    for (int t = 0; t < NT; ++t) {
+      const int ky = SUBPIX ? PY + (t >> 1) : t / 3, kx = SUBPIX ? PX + (t & 1) : t % 3;
+      // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8)
       const unsigned char* bp = base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64;
-      const int o0 = sx[kx], o1 = sx[kx + 4] + 4 * 64;
+      const int o0 = kx == 0 ? sx0 : (kx == 1 ? sx1 : sx2);
+      const int o1 = (kx == 0 ? sx4 : (kx == 1 ? sx5 : sx6)) + 4 * 64;
       const bf16x8 bhi = tr_frag(bp + o0, bp + o1);
       if (NTERMS == 3) {
         const bf16x8 blo = tr_frag(bp + XPART + o0, bp + XPART + o1);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[tap], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[t], 0, 0, 0);
       }
-      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[tap], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[t], 0, 0, 0);
     }
   };
+  auto compute = [&](const unsigned char* base, int ks) __attribute__((always_inline)) {
+    if (!SUBPIX) { compute_p(base, ks, std::integral_constant<int, 0>{}); return; }
+    switch (par) {  // uniform
+      case 0: compute_p(base, ks, std::integral_constant<int, 0>{}); break;
+      case 1: compute_p(base, ks, std::integral_constant<int, 1>{}); break;
+      case 2: compute_p(base, ks, std::integral_constant<int, 2>{}); break;
+      default: compute_p(base, ks, std::integral_constant<int, 3>{}); break;
+    }
+  };
+
   int tile = blockIdx.y;
   if (tile < a.ntiles) {
 #pragma unroll 1
@@ -418,11 +497,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   const int ci = cib * 64 + cih * 32 + r;
   if (ci < a.Cin) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int t = 0; t < NT; ++t) {
+      const int tap = SUBPIX ? (py + (t >> 1)) * 3 + px + (t & 1) : t;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int co = cob * 128 + ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (co < a.Cout) atomicAdd(&a.dwp[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[tap][q]);
+        if (co < a.Cout) atomicAdd(&a.dwp[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[t][q]);
       }
     }
   }
@@ -457,9 +537,84 @@ __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* _
   }
 }
 
+// Sub-pixel weights of "nearest x2 + 3x3": W'[(py,px,co)][ci][ty][tx] = sum of the 3x3 taps that
+// land on low-res offset (ty-1, tx-1) for output parity (py, px); zero outside the 2x2 support.
+//   rows: parity 0 -> ky 0 | ky 1+2 | -      parity 1 -> - | ky 0+1 | ky 2
+__device__ __forceinline__ bool sub_contrib(int par, int t, int k) {
+  return par == 0 ? (t == 0 ? k == 0 : (t == 1 ? k >= 1 : false))
+                  : (t == 0 ? false : (t == 1 ? k <= 1 : k == 2));
+}
+__global__ void subpix_expand_kernel(const float* __restrict__ w, float* __restrict__ we, int Cout,
+                                     int Cin) {
+  const size_t total = (size_t)4 * Cout * Cin * 9;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = i % 9;
+    size_t t = i / 9;
+    const int ci = t % Cin;
+    t /= Cin;
+    const int co = t % Cout, par = t / Cout;
+    const int ty = tap / 3, tx = tap % 3, py = par >> 1, px = par & 1;
+    const float* src = w + ((size_t)co * Cin + ci) * 9;
+    float v = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        if (sub_contrib(py, ty, ky) && sub_contrib(px, tx, kx)) v += src[ky * 3 + kx];
+    we[i] = v;
+  }
+}
+// adjoint of the expansion: dW[co][ci][ky][kx] = sum_parities dWp'[ty*3+tx][par*Cout+co][ci]
+__global__ void subpix_fold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout,
+                                   int Cin) {
+  const size_t total = (size_t)Cout * Cin * 9;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = i % 9;
+    size_t t = i / 9;
+    const int ci = t % Cin, co = t / Cin;
+    const int ky = tap / 3, kx = tap % 3;
+    float v = 0.f;
+#pragma unroll
+    for (int par = 0; par < 4; ++par) {
+      const int py = par >> 1, px = par & 1;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          if (sub_contrib(py, ty, ky) && sub_contrib(px, tx, kx))
+            v += dwp[((size_t)(ty * 3 + tx) * 4 * Cout + (size_t)par * Cout + co) * Cin + ci];
+    }
+    dw[i] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// we[4*Cout][Cin][3][3] = sub-pixel expansion of w[Cout][Cin][3][3] (nearest x2 + 3x3)
+int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream) {
+  EOVAE_CHECK_ARG(w && we && Cout > 0 && Cin > 0, "subpix_expand: bad argument");
+  size_t total = (size_t)4 * Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(subpix_expand_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, we, Cout, Cin);
+  EOVAE_CHECK_LAUNCH("eovae_subpix_expand");
+  return EOVAE_OK;
+}
+
+// dw[Cout][Cin][3][3] from the sub-pixel weight gradient dwp[9][4*Cout][Cin]
+int eovae_subpix_fold(const float* dwp, float* dw, int Cout, int Cin, void* stream) {
+  EOVAE_CHECK_ARG(dwp && dw && Cout > 0 && Cin > 0, "subpix_fold: bad argument");
+  size_t total = (size_t)Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(subpix_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dwp, dw, Cout, Cin);
+  EOVAE_CHECK_LAUNCH("eovae_subpix_fold");
+  return EOVAE_OK;
+}
 
 // number of bf16 elements of the split-packed weight buffer for a 3x3 layer
 size_t eovae_conv3x3_bf16_packed_elems(int Cout, int Cin, int flip) {
@@ -484,21 +639,42 @@ int eovae_conv3x3_bf16_pack(const float* w, void* wp, int Cout, int Cin, int fli
 // 3x3 stride-1 conv (modes NORMAL / UP / ZINS) with split-bf16 operands.
 //   precision: 3 = bf16x3 (fp32-grade), 1 = plain bf16
 // (Cin, Cout) = GEMM K / M channel counts of this call (swapped + flip-packed for a data gradient).
+//   subpix 0: plain.  subpix 1: forward of "nearest x2 + 3x3" in sub-pixel form: x low-res
+//   [N][Cin][Hin][Win], wp = pack(expand(w), flip 0), Cout = the layer's real Cout (multiple of
+//   128), y = [N][Cout][2Hin][2Win] (pass Hout = 2Hin, Wout = 2Win), mode must be 0.
+//   subpix 2: its data gradient: x = dy [N][Cin][Hin][Win] high-res (Cin = the layer's real Cout,
+//   multiple of 16), wp = pack(expand(w), flip 1), output y = dx [N][Cout][Hin/2][Win/2].
 int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                            float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
-                           int mode, int precision, void* stream) {
+                           int mode, int precision, int subpix, void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_bf16_fwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_bf16_fwd: bad shape");
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP || mode == MODE_ZINS,
                   "conv3x3_bf16_fwd: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_fwd: precision %d", precision);
-  const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;
-  EOVAE_CHECK_ARG(Hout == eh && Wout == ew, "conv3x3_bf16_fwd: output %dx%d does not match mode %d",
-                  Hout, Wout, mode);
+  EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_bf16_fwd: subpix %d", subpix);
   ConvBArgs a;
   a.x = x; a.wp = (const unsigned short*)wp; a.bias = bias; a.res = residual; a.y = y;
-  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
-  a.nchunk = cdiv(Cin, 16); a.ncob = cdiv(Cout, 128); a.mode = mode;
+  a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
+  if (subpix == 0) {
+    const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;
+    EOVAE_CHECK_ARG(Hout == eh && Wout == ew, "conv3x3_bf16_fwd: output %dx%d does not match mode %d",
+                    Hout, Wout, mode);
+    a.Cin = Cin; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
+  } else if (subpix == 1) {
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && !residual, "conv3x3_bf16_fwd: subpix 1 needs mode 0, no residual");
+    EOVAE_CHECK_ARG(Cout % 128 == 0, "conv3x3_bf16_fwd: subpix 1 needs Cout %% 128 == 0 (got %d)", Cout);
+    EOVAE_CHECK_ARG(Hout == 2 * Hin && Wout == 2 * Win, "conv3x3_bf16_fwd: subpix 1 output must be 2x");
+    a.Cin = Cin; a.Cout = 4 * Cout; a.creal = Cout; a.cpb = Cout / 128;
+    a.Hout = Hin; a.Wout = Win;  // tiles run over the low-res grid
+  } else {
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && !residual && !bias, "conv3x3_bf16_fwd: subpix 2 is a bare data gradient");
+    EOVAE_CHECK_ARG(Cin % 16 == 0, "conv3x3_bf16_fwd: subpix 2 needs Cin %% 16 == 0 (got %d)", Cin);
+    EOVAE_CHECK_ARG(Hin == 2 * Hout && Win == 2 * Wout, "conv3x3_bf16_fwd: subpix 2 output must be 1/2");
+    a.Cin = 4 * Cin; a.creal = Cin; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
+  }
+  Cin = a.Cin; Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
+  a.nchunk = cdiv(Cin, 16); a.ncob = cdiv(Cout, 128);
   a.tiles_x = cdiv(Wout, 32);
   hipStream_t st = (hipStream_t)stream;
   // 16-row tiles when that still fills the chip (>= 2 blocks per CU), else 8-row tiles
@@ -519,16 +695,26 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
 }
 
 // dwp[9][Cout][Cin] += dY (x) Xv with split-bf16 operands (modes NORMAL / UP of the forward layer)
+//   subpix 1: weight gradient of "nearest x2 + 3x3" in sub-pixel form: x low-res, dy high-res
+//   [N][Cout][2Hin][2Win] (pass Hout = 2Hin, Wout = 2Win), Cout %% 128 == 0, mode 0,
+//   dwp = [9][4*Cout][Cin] pre-zeroed; finish with eovae_subpix_fold.
 int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
                              int Win, int Cout, int Hout, int Wout, int mode, int precision,
-                             void* stream) {
+                             int subpix, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_bf16_wgrad: null pointer");
+  EOVAE_CHECK_ARG(subpix == 0 || subpix == 1, "conv3x3_bf16_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_bf16_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_wgrad: precision %d", precision);
   WgBArgs a;
   a.x = x; a.dy = dy; a.dwp = dwp;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
-  a.mode = mode;
+  a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
+  if (subpix) {
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && Cout % 128 == 0 && Hout == 2 * Hin && Wout == 2 * Win,
+                    "conv3x3_bf16_wgrad: subpix needs mode 0, Cout %% 128 == 0 and a 2x dy");
+    a.creal = Cout; a.cpb = Cout / 128; a.Cout = 4 * Cout; a.Hout = Hin; a.Wout = Win;
+    Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
+  }
   a.tiles_x = cdiv(Wout, 32); a.tiles_y = cdiv(Hout, 2);
   a.ntiles = N * a.tiles_x * a.tiles_y;
   a.ncib = cdiv(Cin, 64);
@@ -540,8 +726,13 @@ int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N,
   if (split > a.ntiles) split = a.ntiles;
   dim3 grid(a.ncib * ncob, split);
   hipStream_t st = (hipStream_t)stream;
-  if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1>), grid, dim3(512), 0, st, a);
+  if (subpix) {
+    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, true>), grid, dim3(512), 0, st, a);
+  } else {
+    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, false>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, false>), grid, dim3(512), 0, st, a);
+  }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_bf16_wgrad");
   return EOVAE_OK;
 }

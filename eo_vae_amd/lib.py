@@ -26,8 +26,10 @@ SIGNATURES = {
     'eovae_conv2d_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     'eovae_conv3x3_bf16_packed_elems': (_sz, [_i, _i, _i]),
     'eovae_conv3x3_bf16_pack': (_i, [_p, _p, _i, _i, _i, _f, _p]),
-    'eovae_conv3x3_bf16_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    'eovae_conv3x3_bf16_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_conv3x3_bf16_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_subpix_expand': (_i, [_p, _p, _i, _i, _p]),
+    'eovae_subpix_fold': (_i, [_p, _p, _i, _i, _p]),
+    'eovae_conv3x3_bf16_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv2d_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv_unpack_wgrad': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_bias_grad': (_i, [_p, _p, _i, _i, _i, _p]),

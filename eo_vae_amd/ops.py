@@ -130,11 +130,81 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
                                          4.0 * (x.numel() + y.numel() + weight.numel()))
         ev0.record()
     L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
-                                       cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION],
+                                       cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], 0,
                                        L.stream()), 'eovae_conv3x3_bf16_fwd')
     if timed:
         ev1.record()
     return y
+
+
+# "nearest x2 + 3x3" as four 2x2 sub-pixel kernels on the low-res grid (4/9 of the MFMA work);
+# needs Cout % 128 == 0 (the 256/512-channel upsample layers of the model), else the plain path.
+SUBPIX_UPSAMPLE = os.environ.get('EOVAE_SUBPIX', '1') != '0'
+
+
+def _subpix_ok(weight):
+    return SUBPIX_UPSAMPLE and CONV_PRECISION != 'f32' and weight.shape[0] % 128 == 0
+
+
+def _subpix_packed(weight, flip):
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    we = torch.empty(4 * cout, cin, 3, 3, dtype=torch.float32, device=weight.device)
+    L.check(lib.eovae_subpix_expand(L.ptr(weight), L.ptr(we), cout, cin, L.stream()), 'eovae_subpix_expand')
+    wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(4 * cout, cin, int(flip)), dtype=torch.bfloat16,
+                     device=weight.device)
+    L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(we), L.ptr(wp), 4 * cout, cin, int(flip), 1.0, L.stream()),
+            'eovae_conv3x3_bf16_pack')
+    return wp
+
+
+def up_conv_subpix(x, weight, bias):
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    wp = _subpix_packed(weight, False)
+    y = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    timed = CONV3X3_TIMER is not None
+    if timed:
+        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
+                                         4.0 * (x.numel() + y.numel() + weight.numel()))
+        ev0.record()
+    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), None, L.ptr(y), n, cin, h, w,
+                                            cout, 2 * h, 2 * w, MODE_NORMAL, _PREC[CONV_PRECISION], 1,
+                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
+    if timed:
+        ev1.record()
+    return y
+
+
+def up_conv_subpix_dgrad(dy, weight, h, w):
+    n, cout = dy.shape[0], dy.shape[1]
+    cin = weight.shape[1]
+    wp = _subpix_packed(weight, True)
+    dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
+    timed = CONV3X3_TIMER is not None
+    if timed:
+        ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
+                                         4.0 * (dy.numel() + dx.numel() + weight.numel()))
+        ev0.record()
+    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(dy), L.ptr(wp), None, None, L.ptr(dx), n, cout, 2 * h, 2 * w,
+                                            cin, h, w, MODE_NORMAL, _PREC[CONV_PRECISION], 2, L.stream()),
+            'eovae_conv3x3_bf16_fwd')
+    if timed:
+        ev1.record()
+    return dx
+
+
+def up_conv_subpix_wgrad(x, dy, weight):
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    lib = L.load()
+    dwp = torch.zeros(9 * 4 * cout * cin, dtype=torch.float32, device=x.device)
+    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout, 2 * h, 2 * w,
+                                         MODE_NORMAL, _PREC[CONV_PRECISION], 1, L.stream()),
+            'eovae_conv3x3_bf16_wgrad')
+    dw = torch.empty_like(weight)
+    L.check(lib.eovae_subpix_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_subpix_fold')
+    return dw
 
 
 def _gemm_prec():
@@ -188,7 +258,9 @@ class Conv2dFn(torch.autograd.Function):
             raise L.EovaeError(f'conv2d: input has {x.shape[1]} channels, weight expects {cin}')
         res = _c(residual) if residual is not None else None
         bias_c = _c(bias) if bias is not None else None
-        if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
+        if ks == 3 and m == MODE_UP and res is None and _subpix_ok(weight):
+            y = up_conv_subpix(x, weight, bias_c)
+        elif ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
             y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False)
         elif ks == 1 and CONV_PRECISION != 'f32':
             y = conv1x1_lowp(x, weight, bias_c, res)
@@ -208,7 +280,10 @@ class Conv2dFn(torch.autograd.Function):
         n, _, h, w = x.shape
         lib = L.load()
         dx = dw = db = None
-        if ctx.needs_input_grad[0] and ks == 3 and CONV_PRECISION != 'f32':
+        subpix = ks == 3 and m == MODE_UP and not ctx.has_res and _subpix_ok(weight)
+        if ctx.needs_input_grad[0] and subpix:
+            dx = up_conv_subpix_dgrad(dy, weight, h, w)
+        elif ctx.needs_input_grad[0] and ks == 3 and CONV_PRECISION != 'f32':
             if m == MODE_NORMAL:
                 dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_NORMAL, True)
             elif m == MODE_DOWN:
@@ -235,13 +310,15 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 L.check(lib.eovae_upsample2x_bwd(L.ptr(du), L.ptr(dx), n, cin, h, w, L.stream()),
                         'eovae_upsample2x_bwd')
-        if ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
+        if ctx.needs_input_grad[1] and subpix:
+            dw = up_conv_subpix_wgrad(x, dy, weight)
+        elif ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
             dw = conv1x1_lowp_wgrad(x, dy)
         elif ctx.needs_input_grad[1]:
             dwp = torch.zeros(ks * ks * cout * cin, dtype=torch.float32, device=x.device)
             if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
                 L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
-                                                     dy.shape[2], dy.shape[3], m, _PREC[CONV_PRECISION],
+                                                     dy.shape[2], dy.shape[3], m, _PREC[CONV_PRECISION], 0,
                                                      L.stream()), 'eovae_conv3x3_bf16_wgrad')
             else:
                 L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,

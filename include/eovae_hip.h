@@ -57,13 +57,21 @@ int eovae_conv2d_fwd(const float* x, const float* wp, const float* bias, const f
 size_t eovae_conv3x3_bf16_packed_elems(int Cout, int Cin, int flip);
 int eovae_conv3x3_bf16_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale,
                             void* stream);
+/* subpix: "nearest x2 + 3x3" (layers.py:47-50) evaluated as four parity kernels with 2x2 support on the
+ * LOW-res grid (4/9 of the MFMAs, pixel-shuffle folded into the epilogue / loader):
+ *   1 = forward  (x low-res, wp = pack(expand(w), flip 0), Cout %% 128 == 0, y = [N][Cout][2Hin][2Win])
+ *   2 = data grad (x = dy high-res [N][Cin][Hin][Win], wp = pack(expand(w), flip 1), y = dx [N][Cout][Hin/2][Win/2]) */
 int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                            float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
-                           int mode, int precision, void* stream);
+                           int mode, int precision, int subpix, void* stream);
+/* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
+ * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
+int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);
+int eovae_subpix_fold(const float* dwp, float* dw, int Cout, int Cin, void* stream);
 /* split-bf16 weight gradient: dwp[9][Cout][Cin] += dy (x) x, modes 0 / 2 of the forward layer */
 int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
                              int Win, int Cout, int Hout, int Wout, int mode, int precision,
-                             void* stream);
+                             int subpix, void* stream);
 /* dwp[tap][Cout][Cin] += sum_{n,pix} dy * x (mode 0/1/2 of the FORWARD layer); caller zero-fills */
 int eovae_conv2d_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
                        int Win, int Cout, int Hout, int Wout, int KS, int mode, void* stream);
