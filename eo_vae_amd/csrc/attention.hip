@@ -195,7 +195,7 @@ int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bia
                       int batch, int M, int N, int K, long long sam, long long sak, long long sbk,
                       long long sbn, long long scm, long long scn, long long batA, long long batB,
                       long long batC, float alpha, int ksplit, int atomic, int precision,
-                      void* stream);
+                      int kb, long long kbA, long long kbB, void* stream);
 
 // precision 0: exact fp32 MFMA GEMM; 1 / 3: bf16 / split-bf16 GEMM (csrc/gemm_bf16x3.hip)
 static int gemm_any(int precision, const float* A, const float* B, float* Cm, int batch, int M, int N,
@@ -206,7 +206,7 @@ static int gemm_any(int precision, const float* A, const float* B, float* Cm, in
     return eovae_gemm_f32(A, B, Cm, batch, M, N, K, sam, sak, sbk, sbn, scm, scn, batA, batB, batC,
                           alpha, stream);
   return eovae_gemm_bf16x3(A, B, Cm, nullptr, nullptr, batch, M, N, K, sam, sak, sbk, sbn, scm, scn,
-                           batA, batB, batC, alpha, 1, 0, precision, stream);
+                           batA, batB, batC, alpha, 1, 0, precision, 1, 0, 0, stream);
 }
 
 // Fused-by-sequence attention forward: P (B x T x T, caller-allocated, kept for backward) and

@@ -22,6 +22,10 @@ struct GemmBArgs {
   long long batA, batB, batC;
   float alpha;
   int tiles_m, tiles_n, ksplit, atomic;
+  // K may be extended over `kb` equally-strided slabs (e.g. the images of a batch for a 1x1
+  // weight gradient): k_total = kb * K, slab j of A/B starts at j*kbA / j*kbB
+  int kb;
+  long long kbA, kbB;
 };
 
 __device__ __forceinline__ void split8g(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -54,8 +58,9 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
   float* C = g.C + bat * g.batC;
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
-  // K range of this block (multiples of the 32-deep stage)
-  const int stages_total = (g.K + KS - 1) / KS;
+  // K range of this block (multiples of the 32-deep stage; stages never straddle a slab)
+  const int stages_slab = (g.K + KS - 1) / KS;
+  const int stages_total = stages_slab * g.kb;
   const int per = (stages_total + g.ksplit - 1) / g.ksplit;
   const int s_beg = ks_id * per;
   int s_end = s_beg + per;
@@ -78,12 +83,15 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
     if (B_KC) { n = t >> 2; oct = t & 3; } else { n = t & (BN - 1); oct = t >> 8; }
   };
   auto load_stage = [&](int s) {
-    const int k0 = s * KS;
+    const int slab = s / stages_slab;
+    const int k0 = (s - slab * stages_slab) * KS;
+    const float* As_ = A + slab * g.kbA;
+    const float* Bs_ = B + slab * g.kbB;
     {
       int m, oct;
       a_task(tid, m, oct);
       const bool okm = m0 + m < g.M;
-      const float* p = A + (long long)(m0 + m) * g.sam + (long long)(k0 + oct * 8) * g.sak;
+      const float* p = As_ + (long long)(m0 + m) * g.sam + (long long)(k0 + oct * 8) * g.sak;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         ar[j] = (okm && k0 + oct * 8 + j < g.K) ? p[(long long)j * g.sak] : 0.f;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
       int n, oct;
       b_task(tid + i * 512, n, oct);
       const bool okn = n0 + n < g.N;
-      const float* p = B + (long long)(n0 + n) * g.sbn + (long long)(k0 + oct * 8) * g.sbk;
+      const float* p = Bs_ + (long long)(n0 + n) * g.sbn + (long long)(k0 + oct * 8) * g.sbk;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         br[i][j] = (okn && k0 + oct * 8 + j < g.K) ? p[(long long)j * g.sbk] : 0.f;
@@ -187,14 +195,16 @@ void launch(const GemmBArgs& g, dim3 grid, hipStream_t st, bool ak, bool bk) {
 
 extern "C" {
 
+// kb > 1 extends K over kb slabs (strides kbA / kbB elements).
 // precision 3 = bf16x3, 1 = bf16.  atomic = 1: C += (caller pre-zeroes C; required when ksplit > 1
 // or when several batches share C through batC = 0).
 int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, const float* res,
                       int batch, int M, int N, int K, long long sam, long long sak, long long sbk,
                       long long sbn, long long scm, long long scn, long long batA, long long batB,
                       long long batC, float alpha, int ksplit, int atomic, int precision,
-                      void* stream) {
+                      int kb, long long kbA, long long kbB, void* stream) {
   EOVAE_CHECK_ARG(A && B && C, "gemm_bf16x3: null pointer");
+  EOVAE_CHECK_ARG(kb >= 1, "gemm_bf16x3: kb %d", kb);
   EOVAE_CHECK_ARG(batch > 0 && M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape");
   EOVAE_CHECK_ARG(sam == 1 || sak == 1, "gemm_bf16x3: A needs a unit stride");
   EOVAE_CHECK_ARG(sbk == 1 || sbn == 1, "gemm_bf16x3: B needs a unit stride");
@@ -207,6 +217,7 @@ int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bia
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.scm = scm; g.scn = scn;
   g.batA = batA; g.batB = batB; g.batC = batC; g.alpha = alpha;
   g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 256); g.ksplit = ksplit; g.atomic = atomic;
+  g.kb = kb; g.kbA = kbA; g.kbB = kbB;
   dim3 grid((unsigned)(batch * ksplit * g.tiles_m * g.tiles_n));
   const bool ak = (sak == 1 && sam != 1), bk = (sbk == 1 && sbn != 1);
   if (precision == 3) launch<3>(g, grid, (hipStream_t)stream, ak, bk);

@@ -40,7 +40,7 @@ SIGNATURES = {
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
     'eovae_softmax_bwd_rows': (_i, [_p, _p, _ll, _i, _p]),
-    'eovae_gemm_bf16x3': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _i, _i, _i, _p]),
+    'eovae_gemm_bf16x3': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _i, _i, _i, _i, _ll, _ll, _p]),
     'eovae_attention_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     'eovae_attention_bwd': (_i, [_p] * 9 + [_i, _i, _i, _f, _i, _p]),
     'eovae_posterior_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),

@@ -218,7 +218,7 @@ def conv1x1_lowp(x, weight, bias, residual):
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
     L.check(L.load().eovae_gemm_bf16x3(L.ptr(weight), L.ptr(x), L.ptr(y), L.ptr(bias), L.ptr(residual), n,
                                        cout, hw, cin, cin, 1, hw, 1, hw, 1, 0, cin * hw, cout * hw, 1.0, 1,
-                                       0, _PREC[CONV_PRECISION], L.stream()), 'eovae_gemm_bf16x3')
+                                       0, _PREC[CONV_PRECISION], 1, 0, 0, L.stream()), 'eovae_gemm_bf16x3')
     return y
 
 
@@ -228,7 +228,7 @@ def conv1x1_lowp_dgrad(dy, weight):
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
     L.check(L.load().eovae_gemm_bf16x3(L.ptr(weight), L.ptr(dy), L.ptr(dx), None, None, n, cin, hw, cout,
                                        1, cin, hw, 1, hw, 1, 0, cout * hw, cin * hw, 1.0, 1, 0,
-                                       _PREC[CONV_PRECISION], L.stream()), 'eovae_gemm_bf16x3')
+                                       _PREC[CONV_PRECISION], 1, 0, 0, L.stream()), 'eovae_gemm_bf16x3')
     return dx
 
 
@@ -237,11 +237,13 @@ def conv1x1_lowp_wgrad(x, dy):
     n, cin, h, w = x.shape
     cout, hw = dy.shape[1], h * w
     dw = torch.zeros(cout, cin, 1, 1, dtype=torch.float32, device=x.device)
+    # K = (image, pixel): the n image slabs are walked inside the kernel; K is cut into ~256 blocks
     tiles = ((cout + 127) // 128) * ((cin + 255) // 256)
-    ksplit = max(1, min(512 // max(1, tiles * n), max(1, hw // 64)))
-    L.check(L.load().eovae_gemm_bf16x3(L.ptr(dy), L.ptr(x), L.ptr(dw), None, None, n, cout, cin, hw, hw, 1,
-                                       1, hw, cin, 1, cout * hw, cin * hw, 0, 1.0, ksplit, 1,
-                                       _PREC[CONV_PRECISION], L.stream()), 'eovae_gemm_bf16x3')
+    stages = n * ((hw + 31) // 32)
+    ksplit = max(1, min(256 // max(1, tiles), stages // 4 if stages >= 8 else 1))
+    L.check(L.load().eovae_gemm_bf16x3(L.ptr(dy), L.ptr(x), L.ptr(dw), None, None, 1, cout, cin, hw, hw, 1,
+                                       1, hw, cin, 1, 0, 0, 0, 1.0, ksplit, 1, _PREC[CONV_PRECISION],
+                                       n, cout * hw, cin * hw, L.stream()), 'eovae_gemm_bf16x3')
     return dw
 
 

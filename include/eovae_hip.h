@@ -106,12 +106,13 @@ int eovae_gemm_f32(const float* A, const float* B, float* C, int batch, int M, i
                    long long scn, long long batA, long long batB, long long batC, float alpha,
                    void* stream);
 /* split-bf16 strided-batched GEMM (csrc/gemm_bf16x3.hip): C (+)= alpha*A*B + bias[m] + res; serves
- * the 1x1 convolutions (fwd / data-grad / batch-reduced weight-grad with atomic = 1) and attention */
+ * the 1x1 convolutions (fwd / data-grad / batch-reduced weight-grad: K extended over kb image slabs,
+ * atomic = 1 when K is split over blocks) and attention */
 int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, const float* res,
                       int batch, int M, int N, int K, long long sam, long long sak, long long sbk,
                       long long sbn, long long scm, long long scn, long long batA, long long batB,
                       long long batC, float alpha, int ksplit, int atomic, int precision,
-                      void* stream);
+                      int kb, long long kbA, long long kbB, void* stream);
 int eovae_softmax_rows(float* s, long long rows, int n, void* stream);
 int eovae_softmax_bwd_rows(const float* p, float* dp, long long rows, int n, void* stream);
 /* p[B][T][T] receives softmax(scale * q^T k) and must be kept for the backward */
