@@ -106,7 +106,10 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (weak scaling)')
-    ap.add_argument('--modality', default='S2RGB')
+    ap.add_argument('--modality', default=None)
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+                    help='cfg2 (default, headline): S2RGB train step L1+KL; cfg3: S2L2A 12-ch train step '
+                         'L1+MS-SSIM+KL; cfg5: S2L2A encode-only (encode_spatial_normalized + running stats)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -120,11 +123,27 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
+    if args.modality is None:
+        args.modality = 'S2RGB' if args.workload == 'cfg2' else 'S2L2A'
+    if args.workload == 'cfg5' and args.batch == 16:
+        args.batch = 64
     wl = WAVELENGTHS[args.modality]
     C = len(wl)
-    model = build_model(C).to(device)
-    model.train()
-    driver = StepDriver(model, world)
+    model = build_model(C, msssim=args.workload == 'cfg3').to(device)
+    if args.workload == 'cfg5':
+        from eo_vae_amd.encode_latents import RunningStats, encode_spatial_norm
+        model.eval()
+        stats = RunningStats(32, device)
+
+        class EncodeDriver:
+            def step(self, batch, i):
+                z = encode_spatial_norm(model, batch['image'], batch['wvs'])
+                stats.update(z)
+                return z.sum()
+        driver = EncodeDriver()
+    else:
+        model.train()
+        driver = StepDriver(model, world)
     g = torch.Generator('cpu').manual_seed(1234 + rank)
     nb = 2  # distinct synthetic batches resident in HBM before the timed region
     batches = [{'image': synthetic_images(args.batch, C, 256, g).to(device),
@@ -181,8 +200,12 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype,
             'data': 'synthetic (seeded low-res Gaussian field x8 bilinear + 0.25 noise, clamp[-2.5,8]); '
                     'random-init weights',
-            'config': {'workload': f'cfg2: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, full '
-                                   'train step (L1 + 1e-6 KL, clip 1.0, Adam, cosine-warmup LR)',
+            'config': {'workload': {'cfg2': f'cfg2: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, full train step '
+                                            '(L1 + 1e-6 KL, clip 1.0, Adam, cosine-warmup LR)',
+                                    'cfg3': f'cfg3: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, full train step '
+                                            '(L1 + MS-SSIM + 1e-6 KL, clip 1.0, Adam)',
+                                    'cfg5': f'cfg5: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, encode-only '
+                                            '(encode_spatial_normalized + running latent statistics)'}[args.workload],
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'conv_path': path},
             'roofline': {'bound': 'mfma', 'kernel': kname,
@@ -196,7 +219,11 @@ def main():
             'hbm_roofline_frac': round(ips / world / r_hbm, 4),
             'final_loss': final_loss,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.workload == 'cfg5':
+            out['metric'] = 'encode-only images/sec (BxCx256x256)'
+            out.pop('hbm_roofline_frac', None)
+            out['step_flops_tflops'] = round(274.6e9 * ips / world / 1e12, 2)
+        if not args.no_cpu_baseline and world == 1 and args.workload == 'cfg2':
             out['cpu_baseline'] = cpu_baseline(C, wl)
         print(json.dumps(out), flush=True)
     if world > 1:
