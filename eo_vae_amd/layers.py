@@ -35,6 +35,10 @@ class GroupNorm(nn.GroupNorm):
     def forward(self, x):
         return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, self.silu)
 
+    def forward_fork(self, x):
+        """-> (normalised+activated x, x for the residual branch); see ops.GroupNormSiluForkFn."""
+        return ops.group_norm_silu_fork(x, self.weight, self.bias, self.num_groups, self.eps, self.silu)
+
 
 class Downsample(nn.Module):  # layers.py:25-37
     def __init__(self, in_channels: int):
@@ -72,8 +76,9 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x, emb=None):
-        h = self.conv1(self.norm1(x))
-        skip = self.nin_shortcut(x) if self.in_channels != self.out_channels else x
+        a, xs = self.norm1.forward_fork(x)
+        h = self.conv1(a)
+        skip = self.nin_shortcut(xs) if self.in_channels != self.out_channels else xs
         return self.conv2(self.norm2(h), residual=skip)
 
 
@@ -90,7 +95,7 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        hn = self.norm(x)
+        hn, x = self.norm.forward_fork(x)
         q = self.q(hn).view(b, c, h * w)
         k = self.k(hn).view(b, c, h * w)
         v = self.v(hn).view(b, c, h * w)

@@ -383,6 +383,48 @@ def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
     return GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu)
 
 
+class GroupNormSiluForkFn(torch.autograd.Function):
+    """(y, x_skip) = (silu(gn(x)), x): the residual branch of a ResnetBlock leaves through this
+    node so that its gradient is folded into the GroupNorm backward kernel (dx = gn_bwd + dskip)
+    instead of a separate elementwise-add pass over the activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        L.require_gpu(x, 'group_norm')
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        n, c, h, w = x.shape
+        lib = L.load()
+        ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, groups), x.device)
+        y = torch.empty_like(x)
+        stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
+        L.check(lib.eovae_gn_silu_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats),
+                                      n, c, h * w, groups, eps, int(silu), L.ptr(ws), L.stream()),
+                'eovae_gn_silu_fwd')
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.groups, ctx.silu = groups, silu
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, gamma, beta, stats = ctx.saved_tensors
+        dy = _c(dy)
+        dskip = _c(dskip) if dskip is not None else None
+        n, c, h, w = x.shape
+        lib = L.load()
+        ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, ctx.groups), x.device)
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        L.check(lib.eovae_gn_silu_bwd(L.ptr(x), L.ptr(dy), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
+                                      L.ptr(dskip), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), n, c, h * w,
+                                      ctx.groups, int(ctx.silu), L.ptr(ws), L.stream()),
+                'eovae_gn_silu_bwd')
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm_silu_fork(x, gamma, beta, groups=32, eps=1e-6, silu=True):
+    return GroupNormSiluForkFn.apply(x, gamma, beta, groups, eps, silu)
+
+
 # ------------------------------------------------------------------------------------------
 # attention core (softmax(Q^T K / sqrt(C)) V on [B, C, T] tensors)
 # ------------------------------------------------------------------------------------------
