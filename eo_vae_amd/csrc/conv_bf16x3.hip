@@ -193,6 +193,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 #ifndef EOVAE_ABL
 #define EOVAE_ABL 0
 #endif
+#ifndef EOVAE_EXP
+#define EOVAE_EXP 0
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for the NEXT chunk's halo loads (issued 1-3 phases ahead on purpose) at the first
+// barrier after they were issued; register uses still get their own counted vmcnt waits.
+#if EOVAE_EXP & 2
+#define LDS_BARRIER()                                      \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)
+#else
+#define LDS_BARRIER() __syncthreads()
+#endif
   // phase p = (chunk, active tap row): one row of taps of one 16-channel chunk
   const int nphase = a.nchunk * kyn;
   for (int p = 0; p < nphase; ++p) {
@@ -224,6 +240,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
         bf16x8 blo;
         if (NTERMS == 3)
           blo = *reinterpret_cast<const bf16x8*>(smem + OFF_XLO + h * (NPX * 16) + pix * 16);
+#if EOVAE_EXP & 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (NTERMS == 3) {
@@ -232,15 +251,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi, acc[i][j], 0, 0, 0);
         }
+#if EOVAE_EXP & 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
 
     if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) store_w(buf ^ 1);  // other buffer: last read in phase p-1, fenced below
     if (kyi == kyn - 1 && chunk + 1 < a.nchunk) {
-      if (!(EOVAE_ABL & 4)) __syncthreads();  // every wave has finished reading this chunk's halo tile
+      if (!(EOVAE_ABL & 4)) LDS_BARRIER();  // every wave has finished reading this chunk's halo tile
       if (!(EOVAE_ABL & 2)) store_x();
     }
-    if (!(EOVAE_ABL & 4)) __syncthreads();
+    if (!(EOVAE_ABL & 4)) LDS_BARRIER();
   }
 
   if (a.subpix == 1) {  // pixel-shuffle store: parity (py,px) block -> y[n][co][2*oy+py][2*ox+px]
