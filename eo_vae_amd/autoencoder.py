@@ -301,11 +301,8 @@ class EOFluxVAE(LightningModule):
     # ------------------------------------------------------------------ training
     def configure_optimizers(self):
         params = [p for net in (self.encoder, self.decoder) for p in net.parameters() if p.requires_grad]
-        if params and params[0].is_cuda:
-            from .optim import FusedAdam
-            opt_ae = FusedAdam(params, lr=self.base_lr)
-        else:  # construction-time / CPU plumbing only; the kernels themselves need the GPU
-            opt_ae = torch.optim.Adam(params, lr=self.base_lr)
+        from .optim import FusedAdam   # raises EovaeError for CPU parameters: no fallback optimiser
+        opt_ae = FusedAdam(params, lr=self.base_lr)
         optimizers, schedulers = [opt_ae], []
         if hasattr(self.loss_fn, 'discriminator'):
             optimizers.append(torch.optim.Adam(self.loss_fn.discriminator.parameters(), lr=self.base_lr))

@@ -82,3 +82,30 @@ class SyntheticDataModule:
         mode = self.val_mode if self.val_mode in WAVELENGTHS else 'random'
         return SyntheticLoader(self.modalities, self.eval_batch_size, self.size, self.val_steps,
                                self.seed + 7919 + self.rank, self.device, mode)
+
+
+# Sentinel-2 L2A statistics of the reference's custom normaliser (terramesh_datamodule.py:141-183)
+S2L2A_MEAN = [1718.9949, 1825.5669, 2043.5834, 2175.4543, 2522.9522, 3114.2216, 3323.3469, 3417.3660,
+              3470.9655, 3489.4869, 2725.9735, 2152.0551]
+S2L2A_STD = [2126.3409, 2140.1035, 2044.6618, 2125.3351, 2065.3251, 1874.4652, 1808.0426, 1839.0210,
+             1737.9521, 1738.5136, 1456.5919, 1365.1743]
+
+
+def prepare_batch(raw: torch.Tensor, mean=None, std=None, clamp=None, target_size=None, hflip=False,
+                  vflip=False, rot=0) -> torch.Tensor:
+    """Fused GPU batch preparation (normalise -> bilinear resize -> D4 augmentation), one HIP
+    kernel; the collate function of the reference does the same with separate host-side torch ops
+    (terramesh_datamodule.py:463-482)."""
+    from . import lib as L
+    L.require_gpu(raw, 'prepare_batch')
+    raw = raw.contiguous()
+    n, c, hs, ws = raw.shape
+    ht, wt = (hs, ws) if target_size is None else (int(target_size[0]), int(target_size[1]))
+    hd, wd = (wt, ht) if rot % 2 else (ht, wt)
+    out = torch.empty(n, c, hd, wd, dtype=torch.float32, device=raw.device)
+    m = None if mean is None else torch.as_tensor(mean, dtype=torch.float32, device=raw.device).contiguous()
+    s = None if std is None else torch.as_tensor(std, dtype=torch.float32, device=raw.device).contiguous()
+    lo, hi = (1.0, 0.0) if clamp is None else (float(clamp[0]), float(clamp[1]))
+    L.check(L.load().eovae_batch_prep(L.ptr(raw), L.ptr(m), L.ptr(s), L.ptr(out), n, c, hs, ws, ht, wt, lo, hi,
+                                      int(hflip), int(vflip), int(rot) % 4, L.stream()), 'eovae_batch_prep')
+    return out

@@ -102,6 +102,55 @@ def _flush(host, ev, path):
     np.savez_compressed(path, latent=host.numpy())
 
 
+@torch.no_grad()
+def encode_split_pairs(model, loader, output_dir, wvs_lr, wvs_hr, stats_lr=None, stats_hr=None,
+                       encode_fn=encode_raw):
+    """The reference's paired (low-res / high-res sensor) contract (encode_latents.py:305-352): batches
+    carry 'image_lr', 'image_hr', 'aoi'; one `<aoi>.npz` per sample with keys lr_latent, hr_latent,
+    lr_image, hr_image -- the layout its Sen2NaipCrossSensorLatent dataset reads back.  Device->host
+    copies of batch i overlap the encode of batch i+1 (pinned staging + event)."""
+    device = next(model.parameters()).device
+    os.makedirs(output_dir, exist_ok=True)
+    wvs_lr, wvs_hr = wvs_lr.to(device), wvs_hr.to(device)
+    pending = None
+
+    def write(aois, tensors, ev):
+        ev.synchronize()
+        z_lr, z_hr, x_lr, x_hr = (t.numpy() for t in tensors)
+        for i, aoi in enumerate(aois):
+            np.savez_compressed(os.path.join(output_dir, f'{aoi}.npz'), lr_latent=z_lr[i], hr_latent=z_hr[i],
+                                lr_image=x_lr[i], hr_image=x_hr[i])
+
+    for batch in loader:
+        lr, hr = batch['image_lr'].to(device), batch['image_hr'].to(device)
+        z_lr, z_hr = encode_fn(model, lr, wvs_lr), encode_fn(model, hr, wvs_hr)
+        if stats_lr is None:
+            stats_lr, stats_hr = RunningStats(z_lr.shape[1], device), RunningStats(z_hr.shape[1], device)
+        stats_lr.update(z_lr)
+        stats_hr.update(z_hr)
+        host = []
+        for t in (z_lr, z_hr, lr, hr):
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            host.append(h)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            write(*pending)
+        pending = (list(batch['aoi']), host, ev)
+    if pending is not None:
+        write(*pending)
+    return stats_lr, stats_hr
+
+
+def write_pair_stats_json(stats_lr: RunningStats, stats_hr: RunningStats, path: str) -> None:
+    """latent_stats.json schema of the reference (encode_latents.py:521-530)."""
+    d = {'lr_latent': {k: v.tolist() for k, v in stats_lr.get_stats_dict().items()},
+         'hr_latent': {k: v.tolist() for k, v in stats_hr.get_stats_dict().items()}}
+    with open(path, 'w') as f:
+        json.dump(d, f, indent=4)
+
+
 def write_stats_json(stats: RunningStats, path: str) -> None:
     d = {k: v.tolist() for k, v in stats.get_stats_dict().items()}
     with open(path, 'w') as f:

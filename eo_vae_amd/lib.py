@@ -55,6 +55,7 @@ SIGNATURES = {
     'eovae_msssim_fwd': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
     'eovae_msssim_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
     'eovae_running_stats_update': (_i, [_p, _p, _i, _i, _i, _p]),
+    'eovae_batch_prep': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _p]),
     'eovae_gradnorm_workspace_bytes': (_sz, []),
     'eovae_grad_norm': (_i, [_p, _sz, _f, _p, _p, _p]),
     'eovae_adam_step': (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _p, _f, _p]),

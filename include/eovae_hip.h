@@ -189,6 +189,16 @@ int eovae_scale_inplace(float* g, size_t n, const float* clip, float s, void* st
  * -------------------------------------------------------------------------------------- */
 int eovae_running_stats_update(const float* z, float* state, int B, int C, int HW, void* stream);
 
+/* ----------------------------------------------------------------------------------------
+ * Batch preparation, the step before the path (csrc/batchprep.hip): clamp + per-band z-score,
+ * bilinear resize (align_corners=False), D4 augmentation, in the reference's order
+ *   terramesh_datamodule.py:130-339 (normalisers), :476-479 (resize), :347-369 (flips / rot90)
+ * dst is [N][C][Ht][Wt] (or [Wt][Ht] when rot is odd).  mean/std NULL = no z-score; lo > hi = no clamp.
+ * -------------------------------------------------------------------------------------- */
+int eovae_batch_prep(const float* src, const float* mean, const float* stdv, float* dst, int N, int C,
+                     int Hs, int Ws, int Ht, int Wt, float lo, float hi, int hflip, int vflip, int rot,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,3 +296,57 @@ trainer: {_target_: lightning.Trainer, max_epochs: 1, limit_val_batches: 2, log_
     import os
     assert os.path.exists(os.path.join(cfg['experiment']['save_dir'], 'last.ckpt'))
     assert os.path.exists(os.path.join(cfg['experiment']['save_dir'], 'metrics.csv'))
+
+
+@pytest.mark.parametrize('hs,ws,ht,wt', [(64, 64, 64, 64), (264, 264, 256, 256), (48, 80, 96, 64)])
+def test_batch_prep_matches_reference_ops(hs, ws, ht, wt, prec):
+    """N2: clamp + z-score -> bilinear resize -> D4 augmentation, vs the torch ops the reference's
+    collate uses, for all 16 D4 draws (terramesh_datamodule.py:187-194, 347-369, 476-479)."""
+    from eo_vae_amd.data import S2L2A_MEAN, S2L2A_STD, prepare_batch
+    g = torch.Generator().manual_seed(3)
+    raw = torch.rand(2, 12, hs, ws, generator=g) * 14000.0 - 1500.0
+    mean, std = torch.tensor(S2L2A_MEAN).view(12, 1, 1), torch.tensor(S2L2A_STD).view(12, 1, 1)
+    ref = (torch.clamp(raw, 0.0, 10000.0) - mean) / std
+    if (hs, ws) != (ht, wt):
+        ref = F.interpolate(ref, size=(ht, wt), mode='bilinear', align_corners=False)
+    for hf in (False, True):
+        for vf in (False, True):
+            for k in range(4):
+                if (ht != wt) and k % 2 and False:
+                    continue
+                r = ref
+                if hf:
+                    r = torch.flip(r, dims=[-1])
+                if vf:
+                    r = torch.flip(r, dims=[-2])
+                if k:
+                    r = torch.rot90(r, k, dims=[-2, -1])
+                out = prepare_batch(raw.cuda(), S2L2A_MEAN, S2L2A_STD, (0.0, 10000.0), (ht, wt), hf, vf, k)
+                assert out.shape == r.shape
+                assert (out.cpu() - r).abs().max().item() < 2e-5, (hf, vf, k)
+
+
+def test_encode_pairs_npz_contract(tmp_path, prec):
+    """N1: per-AOI .npz files + latent_stats.json in the reference's layout (encode_latents.py:345-352,
+    521-530)."""
+    import json
+    import os
+    from oracle import eo_vae_cpu as O
+    from eo_vae_amd.encode_latents import encode_split_pairs, encode_spatial_norm, write_pair_stats_json
+    from tests.test_gpu_model import build_pair
+    oracle, prod = build_pair(O.TINY, 21)
+    oracle.eval(), prod.eval()
+    wvs = torch.tensor([0.665, 0.56, 0.49, 0.842])
+    batches = [{'image_lr': O.synthetic_batch(2, 4, 64, seed=10 + i), 'image_hr': O.synthetic_batch(2, 4, 64, seed=20 + i),
+                'aoi': [f'aoi_{i}_{j}' for j in range(2)]} for i in range(2)]
+    s_lr, s_hr = encode_split_pairs(prod, batches, str(tmp_path), wvs, wvs, encode_fn=encode_spatial_norm)
+    write_pair_stats_json(s_lr, s_hr, str(tmp_path / 'latent_stats.json'))
+    d = np.load(tmp_path / 'aoi_1_0.npz')
+    assert sorted(d.keys()) == ['hr_image', 'hr_latent', 'lr_image', 'lr_latent']
+    assert d['lr_latent'].shape == (32, 8, 8) and d['lr_image'].shape == (4, 64, 64)
+    want = oracle.encode_spatial_normalized(batches[1]['image_lr'], wvs)[0]
+    assert rel(d['lr_latent'], want) < 1e-3
+    js = json.load(open(tmp_path / 'latent_stats.json'))
+    assert set(js) == {'lr_latent', 'hr_latent'} and set(js['lr_latent']) == {'mean', 'std', 'var', 'min', 'max', 'count'}
+    assert js['lr_latent']['count'] == [4 * 8 * 8]
+    assert len(os.listdir(tmp_path)) == 5
