@@ -40,6 +40,9 @@ struct ConvBArgs {
   //                        epilogue pixel-shuffles into y[N][creal][2H][2W]
   //   subpix 2 (data grad): K = 4*creal channels (parity-major) gathered from the high-res dy,
   //                        output = low-res dx; active taps depend on the chunk's parity
+  // space-to-depth form of "pad(0,1,0,1) + 3x3 stride 2" (no MFMA spent on inserted zeros):
+  //   subpix 3 (forward):  K = 4*creal channels gathered from the high-res x at the chunk's parity
+  //   subpix 4 (data grad): M = 4*creal parity-major rows on the low-res dy, pixel-shuffled into dx
   int subpix, creal, cpb;
 };
 
@@ -69,16 +72,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-template <int TH, int NTERMS>
-__global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
-  constexpr int TW = 32, BM = 128, KC = 16;
+template <int TH, int NTERMS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
+  constexpr int TW = 32, BM = 128, KC = 16, NTHR = NW * 64;
   constexpr int XH = TH + 2, XW = TW + 2, NPX = XH * XW;
-  constexpr int NI = TH / 4;                    // pixel-row tiles per wave
+  constexpr int NI = TH / (NW / 2);             // pixel-row tiles per wave
   constexpr int XBYTES = NPX * KC * 2;          // one halo image (hi or lo)
   constexpr int WTAP = 2 * BM * KC * 2;         // hi+lo tile of one tap: 8 KiB
   constexpr int WPHASE = 3 * WTAP;              // one ky row of taps: 24 KiB
   constexpr int XTASKS = NPX * 2;               // (pixel, 8-channel octet)
-  constexpr int XPT = (XTASKS + 511) / 512;
+  constexpr int XPT = (XTASKS + NTHR - 1) / NTHR;
+  constexpr int WPT = 1536 / NTHR;              // 16-byte weight units per thread and phase
   constexpr int OFF_XLO = XBYTES, OFF_W = 2 * XBYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XBYTES + 2 * WPHASE];
 
@@ -94,29 +98,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int wco = (wave & 1) * 64, wrow = (wave >> 1) * NI;
   const size_t in_plane = (size_t)a.Hin * a.Win;
-  const int xch = a.subpix == 2 ? a.creal : a.Cin;  // channels of the stored input tensor
+  const bool kgather = a.subpix == 2 || a.subpix == 3;  // K channels gathered at a parity
+  const bool mshuffle = a.subpix == 1 || a.subpix == 4; // M rows pixel-shuffled on store
+  const int xch = kgather ? a.creal : a.Cin;  // channels of the stored input tensor
   const float* xn = a.x + (size_t)n * xch * in_plane;
-  // active tap window [ky0, ky0+kyn) x [kx0, kx0+kxn): all 9 taps, or the 2x2 support of a parity
-  const int kyn = a.subpix ? 2 : 3, kxn = kyn;
-  const int par1 = a.subpix == 1 ? cob / a.cpb : 0;  // forward: parity of this block's output rows
-  auto parity_of = [&](int chunk) { return a.subpix == 2 ? (chunk * KC) / a.creal : par1; };
-  auto ky0_of = [&](int par) { return a.subpix == 1 ? (par >> 1) : (a.subpix == 2 ? 1 - (par >> 1) : 0); };
-  auto kx0_of = [&](int par) { return a.subpix == 1 ? (par & 1) : (a.subpix == 2 ? 1 - (par & 1) : 0); };
+  // active tap window [ky0, ky0+kyc) x [kx0, kx0+kxc) of a parity; kyn row-phases per chunk
+  const int kyn = a.subpix ? 2 : 3;
+  const int par1 = mshuffle ? cob / a.cpb : 0;  // parity of this block's output rows
+  auto parity_of = [&](int chunk) { return kgather ? (chunk * KC) / a.creal : par1; };
+  auto win0 = [&](int pb) {  // first active tap of an axis whose parity bit is pb
+    switch (a.subpix) {
+      case 1: return pb;          // up fwd:    {py, py+1}
+      case 2: return 1 - pb;      // up dgrad:  {1-py, 2-py}
+      case 3: return 1;           // down fwd:  {1, 2} (py = 0) / {1} (py = 1)
+      case 4: return pb;          // down dgrad: {0, 1} (py = 0) / {1} (py = 1)
+      default: return 0;
+    }
+  };
+  auto wincnt = [&](int pb) { return a.subpix == 0 ? 3 : (a.subpix >= 3 ? 2 - pb : 2); };
 
   float xr[XPT][8];
-  f32x4 wr[3];
+  f32x4 wr[WPT];
 
   // chunk-invariant source offsets of this thread's halo tasks (index math hoisted out of the
   // K loop: it cost ~10 % of the kernel when recomputed per chunk)
   int xsi[XPT];
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
-    const int t = tid + i * 512;
+    const int t = tid + i * NTHR;
     const int g = t / NPX, pix = t - g * NPX;
     const int rr = pix / XW, cc = pix - rr * XW;
     int si = -1;
     if (t < XTASKS) {
-      if (a.subpix == 2) {  // low-res halo pixel (vy, vx) -> index of high-res pixel (2vy, 2vx)
+      if (kgather) {  // low-res halo pixel (vy, vx) -> index of high-res pixel (2vy, 2vx)
         const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
         if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout) si = 2 * vy * a.Win + 2 * vx;
       } else {
@@ -127,14 +141,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   }
   auto load_x = [&](int c0) {
     int cbase = c0, poff = 0;
-    if (a.subpix == 2) {  // channel chunk of parity p reads dy[co][2vy+py][2vx+px]
+    if (kgather) {  // channel chunk of parity p reads src[c][2vy+py][2vx+px]
       const int par = c0 / a.creal;
       cbase = c0 - par * a.creal;
       poff = (par >> 1) * a.Win + (par & 1);
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int g = (tid + i * 512) / NPX;
+      const int g = (tid + i * NTHR) / NPX;
       const int si = xsi[i];
       const float* src = xn + (size_t)(cbase + g * 8) * in_plane + (si >= 0 ? si + poff : 0);
 #pragma unroll
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   auto store_x = [&]() {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int t = tid + i * 512;
+      const int t = tid + i * NTHR;
       if (t < XTASKS) {
         const int g = t / NPX, pix = t - g * NPX;
         bf16x8 hi, lo;
@@ -160,8 +174,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   // phase p = chunk*3 + ky : taps ky*3 .. ky*3+2 of channel chunk `chunk`
   auto load_w = [&](int chunk, int ky) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int u = tid + i * 512;        // 16-byte unit in [0, 1536)
+    for (int i = 0; i < WPT; ++i) {
+      const int u = tid + i * NTHR;       // 16-byte unit in [0, 1536)
       const int tl = u >> 9, within = u & 511;
       const size_t tile = ((size_t)((ky * 3 + tl) * a.nchunk + chunk) * a.ncob + cob);
       wr[i] = *reinterpret_cast<const f32x4*>(
@@ -170,8 +184,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int u = tid + i * 512;
+    for (int i = 0; i < WPT; ++i) {
+      const int u = tid + i * NTHR;
       *reinterpret_cast<f32x4*>(smem + OFF_W + buf * WPHASE + u * 16) = wr[i];
     }
   };
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   load_x(0);
-  load_w(0, ky0_of(parity_of(0)));
+  load_w(0, win0(parity_of(0) >> 1));
   store_x();
   store_w(0);
   __syncthreads();
@@ -214,18 +228,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   for (int p = 0; p < nphase; ++p) {
     const int chunk = p / kyn, kyi = p - chunk * kyn;
     const int par = parity_of(chunk);
-    const int ky = ky0_of(par) + kyi, kx0 = kx0_of(par);
+    const int ky = win0(par >> 1) + kyi, kx0 = win0(par & 1), kxn = wincnt(par & 1);
+    const bool row_active = kyi < wincnt(par >> 1);  // parity-1 axes of the stride-2 forms have 1 tap
     const int buf = p & 1;
     if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) {
       const int nchk = (p + 1) / kyn;
-      load_w(nchk, ky0_of(parity_of(nchk)) + (p + 1 - nchk * kyn));
+      int nky = win0(parity_of(nchk) >> 1) + (p + 1 - nchk * kyn);
+      load_w(nchk, nky > 2 ? 2 : nky);
     }
     if (!(EOVAE_ABL & 2)) if (kyi == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
 
     const unsigned char* wb = smem + OFF_W + buf * WPHASE;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      if (kx < kx0 || kx >= kx0 + kxn) continue;  // uniform: taps outside the parity's 2x2 support
+      if (!row_active || kx < kx0 || kx >= kx0 + kxn) continue;  // uniform: outside the parity's support
       bf16x8 ahi[2], alo[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
     if (!(EOVAE_ABL & 4)) LDS_BARRIER();
   }
 
-  if (a.subpix == 1) {  // pixel-shuffle store: parity (py,px) block -> y[n][co][2*oy+py][2*ox+px]
+  if (mshuffle) {  // pixel-shuffle store: parity (py,px) block -> y[n][co][2*oy+py][2*ox+px]
     const int py = par1 >> 1, px = par1 & 1;
     const size_t out_plane = (size_t)a.Hout * a.Wout * 4;
     const int ox = ox0 + r;
@@ -353,10 +369,12 @@ struct WgBArgs {
   int tiles_x, tiles_y, ntiles, ncib;
   // subpix 1: rows are the 4*creal parity-major output channels of the sub-pixel form; dy is the
   // high-res gradient gathered at the block's parity; only the parity's 2x2 taps are accumulated
+  // subpix 2: columns are the 4*creal parity-major (space-to-depth) input channels of the stride-2
+  // layer; x is the high-res input gathered at the ci-block's parity; taps (1..2, 1..2)
   int subpix, creal, cpb;
 };
 
-template <int NTERMS, bool SUBPIX>
+template <int NTERMS, int SUBPIX>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   constexpr int NT = SUBPIX ? 4 : 9;  // accumulated taps: all 9, or the parity's 2x2 support
   constexpr int PW = 32, XW = 40, XWV = 34, NXP = 4 * XW;  // 2 output rows + halo; LDS row pitch 40
@@ -373,10 +391,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
   const int ct = wave & 3, cih = wave >> 2;
   const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
-  const int par = SUBPIX ? cob / a.cpb : 0, py = par >> 1, px = par & 1;
-  const int dych = SUBPIX ? a.creal : a.Cout;   // channels / plane of the stored dy tensor
+  const int par = SUBPIX == 1 ? cob / a.cpb : (SUBPIX == 2 ? (cib * 64) / a.creal : 0);
+  const int py = par >> 1, px = par & 1;
+  const int dych = SUBPIX == 1 ? a.creal : a.Cout;   // channels / plane of the stored dy tensor
   const size_t in_plane = (size_t)a.Hin * a.Win;
-  const size_t out_plane = SUBPIX ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
+  const size_t out_plane = SUBPIX == 1 ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
   // per-lane byte offsets inside a swizzled [pixel][32 ch] image for the two transposed 4x16 block
   // reads of a fragment (pixel rows lpart and lpart+4 of the 16-pixel k-step, 8-byte chunk lchunk)
   const int lpart = 8 * (g >> 1) + lq, lchunk = 4 * (g & 1) + lp;
@@ -411,12 +430,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels
       const int oy = oy0 + (ks >> 1), ox = ox0 + 16 * (ks & 1) + pixl;
       const bool ok = oy < a.Hout && ox < a.Wout;
-      const size_t pixoff = SUBPIX ? (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px
-                                   : (size_t)oy * a.Wout + ox;
+      const size_t pixoff = SUBPIX == 1 ? (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px
+                                        : (size_t)oy * a.Wout + ox;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int co = cob * 128 + quad * 4 + j;
-        dq[j] = (ok && co < a.Cout) ? a.dy[((size_t)n * dych + (co - (SUBPIX ? par * a.creal : 0))) * out_plane + pixoff]
+        dq[j] = (ok && co < a.Cout) ? a.dy[((size_t)n * dych + (co - (SUBPIX == 1 ? par * a.creal : 0))) * out_plane + pixoff]
                                     : 0.f;
       }
     }
@@ -424,11 +443,23 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       const int t2 = ks * XQ + tid;
       const int oct = t2 / NXP, pix = t2 - oct * NXP;
       const int rr = pix / XW, cc = pix - rr * XW;
-      const int si = cc < XWV ? src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win) : -1;
+      int si = -1;
+      if (cc < XWV) {
+        if (SUBPIX == 2) {  // space-to-depth gather: low-res halo pixel (vy,vx) -> x[2vy+py][2vx+px]
+          const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
+          if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
+            si = (2 * vy + py) * a.Win + 2 * vx + px;
+        } else {
+          si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+        }
+      }
+      const int xch = SUBPIX == 2 ? a.creal : a.Cin;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ci = cib * 64 + oct * 8 + j;
-        xq[j] = (si >= 0 && ci < a.Cin) ? a.x[((size_t)n * a.Cin + ci) * in_plane + si] : 0.f;
+        xq[j] = (si >= 0 && ci < a.Cin)
+                    ? a.x[((size_t)n * xch + (ci - (SUBPIX == 2 ? par * a.creal : 0))) * in_plane + si]
+                    : 0.f;
       }
     }
   };
@@ -468,7 +499,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
     if (NTERMS == 3) alo = tr_frag(ap + DPART + sa0, ap + DPART + sa1);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int ky = SUBPIX ? PY + (t >> 1) : t / 3, kx = SUBPIX ? PX + (t & 1) : t % 3;
+      const int ky = SUBPIX == 1 ? PY + (t >> 1) : (SUBPIX == 2 ? 1 + (t >> 1) : t / 3);
+      const int kx = SUBPIX == 1 ? PX + (t & 1) : (SUBPIX == 2 ? 1 + (t & 1) : t % 3);
+      if (SUBPIX == 2 && (((t >> 1) && PY) || ((t & 1) && PX))) continue;  // compile-time: odd axes have 1 tap
       // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8)
       const unsigned char* bp = base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64;
       const int o0 = kx == 0 ? sx0 : (kx == 1 ? sx1 : sx2);
@@ -520,7 +553,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   if (ci < a.Cin) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int tap = SUBPIX ? (py + (t >> 1)) * 3 + px + (t & 1) : t;
+      const int tap = SUBPIX == 1 ? (py + (t >> 1)) * 3 + px + (t & 1)
+                                  : (SUBPIX == 2 ? (1 + (t >> 1)) * 3 + 1 + (t & 1) : t);
+      if (SUBPIX == 2 && (((t >> 1) && py) || ((t & 1) && px))) continue;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int co = cob * 128 + ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -612,9 +647,75 @@ __global__ void subpix_fold_kernel(const float* __restrict__ dwp, float* __restr
   }
 }
 
+// Space-to-depth forms of "pad(0,1,0,1) + 3x3 stride 2":
+//   forward  : y = conv3x3(xs, W'')   xs[(py,px,ci)] = x[ci][2i+py][2j+px]
+//              W''[co][(py,px,ci)][1+a][1+b] = W[co][ci][2a+py][2b+px]        (a, b in {0,1})
+//   data grad: dx[ci][2i+py][2j+px] = conv3x3(dy, Wd'')[(py,px,ci)]
+//              Wd''[(py,px,ci)][co][1-a][1-b] = W[co][ci][2a+py][2b+px]
+__global__ void down_expand_kernel(const float* __restrict__ w, float* __restrict__ we, int Cout,
+                                   int Cin, int dgrad) {
+  const size_t total = (size_t)4 * Cout * Cin * 9;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = i % 9, ty = tap / 3, tx = tap % 3;
+    size_t t = i / 9;
+    int co, ci, par;
+    if (dgrad) {  // [4Cin][Cout][9]
+      co = t % Cout; t /= Cout;
+      ci = t % Cin; par = t / Cin;
+    } else {      // [Cout][4Cin][9]
+      ci = t % Cin; t /= Cin;
+      par = t % 4; co = t / 4;
+    }
+    const int py = par >> 1, px = par & 1;
+    const int a = dgrad ? 1 - ty : ty - 1, b = dgrad ? 1 - tx : tx - 1;
+    const int ky = 2 * a + py, kx = 2 * b + px;
+    float v = 0.f;
+    if (a >= 0 && a <= 1 && b >= 0 && b <= 1 && ky <= 2 && kx <= 2)
+      v = w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+    we[i] = v;
+  }
+}
+// dW[co][ci][ky][kx] = dwp''[(1+(ky>>1))*3 + 1+(kx>>1)][co][((ky&1)*2+(kx&1))*Cin + ci]
+__global__ void down_fold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout,
+                                 int Cin) {
+  const size_t total = (size_t)Cout * Cin * 9;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = i % 9, ky = tap / 3, kx = tap % 3;
+    size_t t = i / 9;
+    const int ci = t % Cin, co = t / Cin;
+    const int tp = (1 + (ky >> 1)) * 3 + 1 + (kx >> 1), par = (ky & 1) * 2 + (kx & 1);
+    dw[i] = dwp[((size_t)tp * Cout + co) * (4 * (size_t)Cin) + (size_t)par * Cin + ci];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// Space-to-depth weights of the stride-2 layer: dgrad = 0 -> we[Cout][4*Cin][3][3] (forward),
+// dgrad = 1 -> we[4*Cin][Cout][3][3] (data gradient, already in forward-conv orientation)
+int eovae_down_expand(const float* w, float* we, int Cout, int Cin, int dgrad, void* stream) {
+  EOVAE_CHECK_ARG(w && we && Cout > 0 && Cin > 0, "down_expand: bad argument");
+  size_t total = (size_t)4 * Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(down_expand_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, we, Cout, Cin, dgrad);
+  EOVAE_CHECK_LAUNCH("eovae_down_expand");
+  return EOVAE_OK;
+}
+
+// dw[Cout][Cin][3][3] from the space-to-depth weight gradient dwp[9][Cout][4*Cin]
+int eovae_down_fold(const float* dwp, float* dw, int Cout, int Cin, void* stream) {
+  EOVAE_CHECK_ARG(dwp && dw && Cout > 0 && Cin > 0, "down_fold: bad argument");
+  size_t total = (size_t)Cout * Cin * 9;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(down_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dwp, dw, Cout, Cin);
+  EOVAE_CHECK_LAUNCH("eovae_down_fold");
+  return EOVAE_OK;
+}
 
 // we[4*Cout][Cin][3][3] = sub-pixel expansion of w[Cout][Cin][3][3] (nearest x2 + 3x3)
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream) {
@@ -674,7 +775,7 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP || mode == MODE_ZINS,
                   "conv3x3_bf16_fwd: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_fwd: precision %d", precision);
-  EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_bf16_fwd: subpix %d", subpix);
+  EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 4, "conv3x3_bf16_fwd: subpix %d", subpix);
   ConvBArgs a;
   a.x = x; a.wp = (const unsigned short*)wp; a.bias = bias; a.res = residual; a.y = y;
   a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
@@ -689,28 +790,45 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
     EOVAE_CHECK_ARG(Hout == 2 * Hin && Wout == 2 * Win, "conv3x3_bf16_fwd: subpix 1 output must be 2x");
     a.Cin = Cin; a.Cout = 4 * Cout; a.creal = Cout; a.cpb = Cout / 128;
     a.Hout = Hin; a.Wout = Win;  // tiles run over the low-res grid
-  } else {
-    EOVAE_CHECK_ARG(mode == MODE_NORMAL && !residual && !bias, "conv3x3_bf16_fwd: subpix 2 is a bare data gradient");
-    EOVAE_CHECK_ARG(Cin % 16 == 0, "conv3x3_bf16_fwd: subpix 2 needs Cin %% 16 == 0 (got %d)", Cin);
-    EOVAE_CHECK_ARG(Hin == 2 * Hout && Win == 2 * Wout, "conv3x3_bf16_fwd: subpix 2 output must be 1/2");
+  } else if (subpix == 2 || subpix == 3) {
+    // 2: data gradient of the upsample layer; 3: forward of the stride-2 layer.  Both gather the
+    // K channels of chunk parity p from the high-res source x[N][Cin][Hin][Win].
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && !residual, "conv3x3_bf16_fwd: subpix %d needs mode 0, no residual", subpix);
+    EOVAE_CHECK_ARG(Cin % 16 == 0, "conv3x3_bf16_fwd: subpix %d needs Cin %% 16 == 0 (got %d)", subpix, Cin);
+    EOVAE_CHECK_ARG(Hin == 2 * Hout && Win == 2 * Wout, "conv3x3_bf16_fwd: subpix %d output must be 1/2", subpix);
     a.Cin = 4 * Cin; a.creal = Cin; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
+  } else {
+    // 4: data gradient of the stride-2 layer: x = dy low-res, y = dx [N][Cout][2Hin][2Win]
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && !residual && !bias, "conv3x3_bf16_fwd: subpix 4 is a bare data gradient");
+    EOVAE_CHECK_ARG(Cout % 128 == 0, "conv3x3_bf16_fwd: subpix 4 needs Cout %% 128 == 0 (got %d)", Cout);
+    EOVAE_CHECK_ARG(Hout == 2 * Hin && Wout == 2 * Win, "conv3x3_bf16_fwd: subpix 4 output must be 2x");
+    a.Cin = Cin; a.Cout = 4 * Cout; a.creal = Cout; a.cpb = Cout / 128;
+    a.Hout = Hin; a.Wout = Win;
   }
   Cin = a.Cin; Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
   a.nchunk = cdiv(Cin, 16); a.ncob = cdiv(Cout, 128);
   a.tiles_x = cdiv(Wout, 32);
   hipStream_t st = (hipStream_t)stream;
+#ifndef EOVAE_CONV_NW4
+#define EOVAE_CONV_NW4 0
+#endif
   // 16-row tiles when that still fills the chip (>= 2 blocks per CU), else 8-row tiles
   const long long blocks16 = (long long)N * cdiv(Hout, 16) * a.tiles_x * a.ncob;
-  if (blocks16 >= 512) {
+  if (EOVAE_CONV_NW4) {  // two independent 4-wave blocks of 8 x 32 pixels per CU
+    a.tiles_y = cdiv(Hout, 8);
+    dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
+    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 3, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 1, 4>), grid, dim3(256), 0, st, a);
+  } else if (blocks16 >= 512) {
     a.tiles_y = cdiv(Hout, 16);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
-    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 3>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 1>), grid, dim3(512), 0, st, a);
+    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 3, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 1, 8>), grid, dim3(512), 0, st, a);
   } else {
     a.tiles_y = cdiv(Hout, 8);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
-    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 3>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 1>), grid, dim3(512), 0, st, a);
+    if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 3, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 1, 8>), grid, dim3(512), 0, st, a);
   }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_bf16_fwd");
   return EOVAE_OK;
@@ -724,18 +842,23 @@ int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N,
                              int Win, int Cout, int Hout, int Wout, int mode, int precision,
                              int subpix, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_bf16_wgrad: null pointer");
-  EOVAE_CHECK_ARG(subpix == 0 || subpix == 1, "conv3x3_bf16_wgrad: subpix %d", subpix);
+  EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_bf16_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_bf16_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_wgrad: precision %d", precision);
   WgBArgs a;
   a.x = x; a.dy = dy; a.dwp = dwp;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
   a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
-  if (subpix) {
+  if (subpix == 1) {
     EOVAE_CHECK_ARG(mode == MODE_NORMAL && Cout % 128 == 0 && Hout == 2 * Hin && Wout == 2 * Win,
-                    "conv3x3_bf16_wgrad: subpix needs mode 0, Cout %% 128 == 0 and a 2x dy");
+                    "conv3x3_bf16_wgrad: subpix 1 needs mode 0, Cout %% 128 == 0 and a 2x dy");
     a.creal = Cout; a.cpb = Cout / 128; a.Cout = 4 * Cout; a.Hout = Hin; a.Wout = Win;
     Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
+  } else if (subpix == 2) {  // stride-2 layer: x high-res, dy low-res, dwp = [9][Cout][4*Cin]
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && Cin % 64 == 0 && Hin == 2 * Hout && Win == 2 * Wout,
+                    "conv3x3_bf16_wgrad: subpix 2 needs mode 0, Cin %% 64 == 0 and a 1/2 dy");
+    a.creal = Cin; a.Cin = 4 * Cin;
+    Cin = a.Cin;
   }
   a.tiles_x = cdiv(Wout, 32); a.tiles_y = cdiv(Hout, 2);
   a.ntiles = N * a.tiles_x * a.tiles_y;
@@ -748,12 +871,15 @@ int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N,
   if (split > a.ntiles) split = a.ntiles;
   dim3 grid(a.ncib * ncob, split);
   hipStream_t st = (hipStream_t)stream;
-  if (subpix) {
-    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, true>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, true>), grid, dim3(512), 0, st, a);
+  if (subpix == 1) {
+    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 1>), grid, dim3(512), 0, st, a);
+  } else if (subpix == 2) {
+    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, 2>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 2>), grid, dim3(512), 0, st, a);
   } else {
-    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, false>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, false>), grid, dim3(512), 0, st, a);
+    if (precision == 3) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<3, 0>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 0>), grid, dim3(512), 0, st, a);
   }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_bf16_wgrad");
   return EOVAE_OK;

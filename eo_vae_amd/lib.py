@@ -28,6 +28,8 @@ SIGNATURES = {
     'eovae_conv3x3_bf16_pack': (_i, [_p, _p, _i, _i, _i, _f, _p]),
     'eovae_conv3x3_bf16_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_subpix_expand': (_i, [_p, _p, _i, _i, _p]),
+    'eovae_down_expand': (_i, [_p, _p, _i, _i, _i, _p]),
+    'eovae_down_fold': (_i, [_p, _p, _i, _i, _p]),
     'eovae_subpix_fold': (_i, [_p, _p, _i, _i, _p]),
     'eovae_conv3x3_bf16_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv2d_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -158,6 +158,62 @@ def _subpix_packed(weight, flip):
     return wp
 
 
+def _down_ok(x, weight):
+    cout, cin = weight.shape[0], weight.shape[1]
+    return (SUBPIX_UPSAMPLE and CONV_PRECISION != 'f32' and cin % 128 == 0 and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0)
+
+
+def _down_packed(weight, dgrad):
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    we = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=weight.device)
+    L.check(lib.eovae_down_expand(L.ptr(weight), L.ptr(we), cout, cin, int(dgrad), L.stream()),
+            'eovae_down_expand')
+    rows, cols = (4 * cin, cout) if dgrad else (cout, 4 * cin)   # as a forward layer [rows][cols][3][3]
+    wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(rows, cols, 0), dtype=torch.bfloat16,
+                     device=weight.device)
+    L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(we), L.ptr(wp), rows, cols, 0, 1.0, L.stream()),
+            'eovae_conv3x3_bf16_pack')
+    return wp
+
+
+def down_conv_s2d(x, weight, bias):
+    """pad(0,1,0,1) + 3x3 stride 2 in space-to-depth form (K = 4*Cin gathered at the chunk parity)."""
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    wp = _down_packed(weight, False)
+    y = torch.empty(n, cout, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), None, L.ptr(y), n, cin, h, w,
+                                            cout, h // 2, w // 2, MODE_NORMAL, _PREC[CONV_PRECISION], 3,
+                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
+    return y
+
+
+def down_conv_s2d_dgrad(dy, weight, h, w):
+    n, cout = dy.shape[0], dy.shape[1]
+    cin = weight.shape[1]
+    wp = _down_packed(weight, True)
+    dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
+    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(dy), L.ptr(wp), None, None, L.ptr(dx), n, cout, h // 2, w // 2,
+                                            cin, h, w, MODE_NORMAL, _PREC[CONV_PRECISION], 4, L.stream()),
+            'eovae_conv3x3_bf16_fwd')
+    return dx
+
+
+def down_conv_s2d_wgrad(x, dy, weight):
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    lib = L.load()
+    dwp = torch.zeros(9 * cout * 4 * cin, dtype=torch.float32, device=x.device)
+    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout, h // 2, w // 2,
+                                         MODE_NORMAL, _PREC[CONV_PRECISION], 2, L.stream()),
+            'eovae_conv3x3_bf16_wgrad')
+    dw = torch.empty_like(weight)
+    L.check(lib.eovae_down_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_down_fold')
+    return dw
+
+
 def up_conv_subpix(x, weight, bias):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
@@ -262,6 +318,8 @@ class Conv2dFn(torch.autograd.Function):
         bias_c = _c(bias) if bias is not None else None
         if ks == 3 and m == MODE_UP and res is None and _subpix_ok(weight):
             y = up_conv_subpix(x, weight, bias_c)
+        elif ks == 3 and m == MODE_DOWN and res is None and _down_ok(x, weight):
+            y = down_conv_s2d(x, weight, bias_c)
         elif ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
             y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False)
         elif ks == 1 and CONV_PRECISION != 'f32':
@@ -283,8 +341,11 @@ class Conv2dFn(torch.autograd.Function):
         lib = L.load()
         dx = dw = db = None
         subpix = ks == 3 and m == MODE_UP and not ctx.has_res and _subpix_ok(weight)
+        s2d = ks == 3 and m == MODE_DOWN and not ctx.has_res and _down_ok(x, weight)
         if ctx.needs_input_grad[0] and subpix:
             dx = up_conv_subpix_dgrad(dy, weight, h, w)
+        elif ctx.needs_input_grad[0] and s2d:
+            dx = down_conv_s2d_dgrad(dy, weight, h, w)
         elif ctx.needs_input_grad[0] and ks == 3 and CONV_PRECISION != 'f32':
             if m == MODE_NORMAL:
                 dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_NORMAL, True)
@@ -314,6 +375,8 @@ class Conv2dFn(torch.autograd.Function):
                         'eovae_upsample2x_bwd')
         if ctx.needs_input_grad[1] and subpix:
             dw = up_conv_subpix_wgrad(x, dy, weight)
+        elif ctx.needs_input_grad[1] and s2d:
+            dw = down_conv_s2d_wgrad(x, dy, weight)
         elif ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
             dw = conv1x1_lowp_wgrad(x, dy)
         elif ctx.needs_input_grad[1]:

@@ -68,6 +68,13 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);
 int eovae_subpix_fold(const float* dwp, float* dw, int Cout, int Cin, void* stream);
+/* Space-to-depth form of "F.pad(0,1,0,1) + 3x3 stride 2" (layers.py:33-37) on the same kernels, so no
+ * MFMA is spent on inserted zeros:  conv3x3_bf16_fwd subpix 3 = forward (x high-res, wp =
+ * pack(down_expand(w, 0)) as a [Cout][4*Cin] layer), subpix 4 = data gradient (x = dy low-res, wp =
+ * pack(down_expand(w, 1)) as a [4*Cin][Cout] layer, y = dx high-res); conv3x3_bf16_wgrad subpix 2 =
+ * weight gradient into dwp[9][Cout][4*Cin], finished by down_fold. */
+int eovae_down_expand(const float* w, float* we, int Cout, int Cin, int dgrad, void* stream);
+int eovae_down_fold(const float* dwp, float* dw, int Cout, int Cin, void* stream);
 /* split-bf16 weight gradient: dwp[9][Cout][Cin] += dy (x) x, modes 0 / 2 of the forward layer */
 int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
                              int Win, int Cout, int Hout, int Wout, int mode, int precision,

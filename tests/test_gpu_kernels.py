@@ -109,7 +109,8 @@ def test_fails_loudly_on_cpu_tensor():
 LOWP_CASES = [(2, 32, 32, 16, 16, 'normal'), (1, 128, 128, 64, 64, 'normal'), (2, 3, 128, 24, 40, 'normal'),
               (2, 128, 3, 24, 40, 'normal'), (1, 13, 128, 9, 33, 'normal'), (1, 256, 64, 16, 16, 'normal'),
               (4, 512, 512, 32, 32, 'normal'), (2, 32, 32, 16, 16, 'down'), (2, 32, 32, 8, 8, 'up'),
-              (1, 256, 256, 32, 32, 'up'), (2, 64, 128, 12, 20, 'up'), (1, 512, 256, 16, 16, 'up')]
+              (1, 256, 256, 32, 32, 'up'), (2, 64, 128, 12, 20, 'up'), (1, 512, 256, 16, 16, 'up'),
+              (2, 128, 128, 32, 32, 'down'), (1, 256, 256, 24, 40, 'down'), (1, 128, 64, 64, 64, 'down')]
 
 
 @pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
