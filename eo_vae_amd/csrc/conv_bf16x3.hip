@@ -363,6 +363,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 struct WgBArgs {
   const float* x;
   const float* dy;
+  float* db;   // [Cout] bias gradient (sum of dy over n, pixels), pre-zeroed, or null
   float* dwp;  // [9][Cout][Cin] fp32, pre-zeroed
   int N, Cin, Hin, Win, Cout, Hout, Wout;
   int mode;
@@ -419,6 +420,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   // the other LDS buffer after them.  dY is staged by ALL 512 threads (4 channels x 1 pixel
   // each), the X halo by the first 272 (8 channels x 1 pixel).
   float dyr[1][4], xr[1][8];
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};  // bias-gradient partials of this thread's 4 channels
+  const bool do_db = a.db != nullptr && cib == 0 && SUBPIX != 1;
   auto issue = [&](int tile, int ks, float (&dq)[4], float (&xq)[8]) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % a.tiles_x;
@@ -478,6 +481,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
       const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
       *reinterpret_cast<bf16x4v*>(base + off) = hi;
       if (NTERMS == 3) *reinterpret_cast<bf16x4v*>(base + DPART + off) = lo;
+      if (do_db) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dbs[j] += dq[j];
+      }
     }
     if (tid < XQ) {
       const int t2 = ks * XQ + tid;
@@ -549,6 +556,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
     cur ^= 1;
   }
 
+  if (do_db) {  // lanes 16q..16q+15 hold the same 4 channels at 16 different pixels
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = dbs[j];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      const int co = cob * 128 + (tid >> 4) * 4 + j;
+      if ((tid & 15) == 0 && co < a.Cout) atomicAdd(&a.db[co], v);
+    }
+  }
   const int ci = cib * 64 + cih * 32 + r;
   if (ci < a.Cin) {
 #pragma unroll
@@ -838,15 +855,18 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
 //   subpix 1: weight gradient of "nearest x2 + 3x3" in sub-pixel form: x low-res, dy high-res
 //   [N][Cout][2Hin][2Win] (pass Hout = 2Hin, Wout = 2Win), Cout %% 128 == 0, mode 0,
 //   dwp = [9][4*Cout][Cin] pre-zeroed; finish with eovae_subpix_fold.
-int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
-                             int Win, int Cout, int Hout, int Wout, int mode, int precision,
+//   db (may be NULL): [Cout] pre-zeroed; receives the bias gradient sum(dy) from the dy tiles the kernel
+//   stages anyway (not available with subpix 1, where dy is gathered per parity).
+int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, float* db, int N, int Cin,
+                             int Hin, int Win, int Cout, int Hout, int Wout, int mode, int precision,
                              int subpix, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_bf16_wgrad: null pointer");
+  EOVAE_CHECK_ARG(!(db && subpix == 1), "conv3x3_bf16_wgrad: db is not produced in subpix 1");
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_bf16_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_bf16_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(precision == 1 || precision == 3, "conv3x3_bf16_wgrad: precision %d", precision);
   WgBArgs a;
-  a.x = x; a.dy = dy; a.dwp = dwp;
+  a.x = x; a.dy = dy; a.dwp = dwp; a.db = db;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
   a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
   if (subpix == 1) {

@@ -31,7 +31,7 @@ SIGNATURES = {
     'eovae_down_expand': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_down_fold': (_i, [_p, _p, _i, _i, _p]),
     'eovae_subpix_fold': (_i, [_p, _p, _i, _i, _p]),
-    'eovae_conv3x3_bf16_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_conv3x3_bf16_wgrad': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv2d_wgrad': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv_unpack_wgrad': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_bias_grad': (_i, [_p, _p, _i, _i, _i, _p]),

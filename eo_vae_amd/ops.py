@@ -201,13 +201,13 @@ def down_conv_s2d_dgrad(dy, weight, h, w):
     return dx
 
 
-def down_conv_s2d_wgrad(x, dy, weight):
+def down_conv_s2d_wgrad(x, dy, weight, db=None):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * cout * 4 * cin, dtype=torch.float32, device=x.device)
-    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout, h // 2, w // 2,
-                                         MODE_NORMAL, _PREC[CONV_PRECISION], 2, L.stream()),
+    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w, cout, h // 2,
+                                         w // 2, MODE_NORMAL, _PREC[CONV_PRECISION], 2, L.stream()),
             'eovae_conv3x3_bf16_wgrad')
     dw = torch.empty_like(weight)
     L.check(lib.eovae_down_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_down_fold')
@@ -255,7 +255,7 @@ def up_conv_subpix_wgrad(x, dy, weight):
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * 4 * cout * cin, dtype=torch.float32, device=x.device)
-    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout, 2 * h, 2 * w,
+    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), None, n, cin, h, w, cout, 2 * h, 2 * w,
                                          MODE_NORMAL, _PREC[CONV_PRECISION], 1, L.stream()),
             'eovae_conv3x3_bf16_wgrad')
     dw = torch.empty_like(weight)
@@ -340,6 +340,7 @@ class Conv2dFn(torch.autograd.Function):
         n, _, h, w = x.shape
         lib = L.load()
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         subpix = ks == 3 and m == MODE_UP and not ctx.has_res and _subpix_ok(weight)
         s2d = ks == 3 and m == MODE_DOWN and not ctx.has_res and _down_ok(x, weight)
         if ctx.needs_input_grad[0] and subpix:
@@ -376,15 +377,19 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and subpix:
             dw = up_conv_subpix_wgrad(x, dy, weight)
         elif ctx.needs_input_grad[1] and s2d:
-            dw = down_conv_s2d_wgrad(x, dy, weight)
+            if want_db:
+                db = torch.zeros(cout, dtype=torch.float32, device=x.device)
+            dw = down_conv_s2d_wgrad(x, dy, weight, db)
         elif ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
             dw = conv1x1_lowp_wgrad(x, dy)
         elif ctx.needs_input_grad[1]:
             dwp = torch.zeros(ks * ks * cout * cin, dtype=torch.float32, device=x.device)
             if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
-                L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
-                                                     dy.shape[2], dy.shape[3], m, _PREC[CONV_PRECISION], 0,
-                                                     L.stream()), 'eovae_conv3x3_bf16_wgrad')
+                if want_db:  # bias gradient rides on the dy tiles the wgrad kernel stages anyway
+                    db = torch.zeros(cout, dtype=torch.float32, device=x.device)
+                L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w,
+                                                     cout, dy.shape[2], dy.shape[3], m, _PREC[CONV_PRECISION],
+                                                     0, L.stream()), 'eovae_conv3x3_bf16_wgrad')
             else:
                 L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
                                                dy.shape[2], dy.shape[3], ks, m, L.stream()),
@@ -392,7 +397,7 @@ class Conv2dFn(torch.autograd.Function):
             dw = torch.empty_like(weight)
             L.check(lib.eovae_conv_unpack_wgrad(L.ptr(dwp), L.ptr(dw), cout, cin, ks, L.stream()),
                     'eovae_conv_unpack_wgrad')
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
             L.check(lib.eovae_bias_grad(L.ptr(dy), L.ptr(db), n, cout, dy.shape[2] * dy.shape[3],
                                         L.stream()), 'eovae_bias_grad')

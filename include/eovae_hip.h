@@ -75,9 +75,10 @@ int eovae_subpix_fold(const float* dwp, float* dw, int Cout, int Cin, void* stre
  * weight gradient into dwp[9][Cout][4*Cin], finished by down_fold. */
 int eovae_down_expand(const float* w, float* we, int Cout, int Cin, int dgrad, void* stream);
 int eovae_down_fold(const float* dwp, float* dw, int Cout, int Cin, void* stream);
-/* split-bf16 weight gradient: dwp[9][Cout][Cin] += dy (x) x, modes 0 / 2 of the forward layer */
-int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
-                             int Win, int Cout, int Hout, int Wout, int mode, int precision,
+/* split-bf16 weight gradient: dwp[9][Cout][Cin] += dy (x) x, modes 0 / 2 of the forward layer;
+ * db (nullable, pre-zeroed [Cout]) also receives the bias gradient sum(dy) (not with subpix 1) */
+int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, float* db, int N, int Cin,
+                             int Hin, int Win, int Cout, int Hout, int Wout, int mode, int precision,
                              int subpix, void* stream);
 /* dwp[tap][Cout][Cin] += sum_{n,pix} dy * x (mode 0/1/2 of the FORWARD layer); caller zero-fills */
 int eovae_conv2d_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,

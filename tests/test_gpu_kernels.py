@@ -149,3 +149,4 @@ def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol):
     assert rel_err(yg, yr) < tol
     assert rel_err(xg.grad, xr.grad) < tol
     assert rel_err(wg.grad, wr.grad) < max(tol, 2e-5)
+    assert rel_err(bg.grad, br.grad) < 2e-5      # fp32 sums of dy (fused into the wgrad kernel)

@@ -29,5 +29,5 @@ for prec in sys.argv[1:] or ['bf16x3']:
         y = torch.empty_like(dy)
         t_f = timeit(lambda: lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, cin, hw, hw, cout, hw, hw, 0, p, 0, L.stream()))
         dwp = torch.zeros(9 * cout * cin, device='cuda')
-        t_w = timeit(lambda: lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), B, cin, hw, hw, cout, hw, hw, 0, p, 0, L.stream()))
+        t_w = timeit(lambda: lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), None, B, cin, hw, hw, cout, hw, hw, 0, p, 0, L.stream()))
         print(f'{prec:7s} {cin:4d}->{cout:4d} @{hw:3d}^2  fwd {t_f:7.3f} ms {flops/t_f/1e9:7.1f} TF | wgrad {t_w:7.3f} ms {flops/t_w/1e9:7.1f} TF', flush=True)

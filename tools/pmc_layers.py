@@ -15,5 +15,5 @@ for cin, cout, hw in [(128, 128, 256), (512, 512, 64), (512, 512, 32)]:
     dwp = torch.zeros(9 * cout * cin, device='cuda')
     for _ in range(2):
         lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, cin, hw, hw, cout, hw, hw, 0, 3, 0, L.stream())
-        lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), B, cin, hw, hw, cout, hw, hw, 0, 3, 0, L.stream())
+        lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), None, B, cin, hw, hw, cout, hw, hw, 0, 3, 0, L.stream())
     torch.cuda.synchronize()

@@ -29,6 +29,6 @@ for c, hw in [(512, 32), (512, 64), (256, 128)]:
             td = timeit(lambda: ops.conv3x3_lowp(dy, w, None, None, c, ops.MODE_NORMAL, True))
             def wg():
                 dwp = torch.zeros(9 * c * c, device='cuda')
-                ops.L.load().eovae_conv3x3_bf16_wgrad(ops.L.ptr(x), ops.L.ptr(dy), ops.L.ptr(dwp), B, c, hw, hw, c, 2*hw, 2*hw, ops.MODE_UP, 3, 0, ops.L.stream())
+                ops.L.load().eovae_conv3x3_bf16_wgrad(ops.L.ptr(x), ops.L.ptr(dy), ops.L.ptr(dwp), None, B, c, hw, hw, c, 2*hw, 2*hw, ops.MODE_UP, 3, 0, ops.L.stream())
             tw = timeit(wg)
         print(f'{c}ch {hw}->{2*hw} subpix={sub}: fwd {tf:.3f} ms ({flops/tf/1e9:.0f} TF alg) dgrad {td:.3f} ms ({flops/td/1e9:.0f}) wgrad {tw:.3f} ms ({flops/tw/1e9:.0f})', flush=True)
