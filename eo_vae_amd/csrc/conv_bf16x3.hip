@@ -416,84 +416,99 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
-  // staging registers: a quarter tile is issued before a k-step's 27 MFMAs and committed to
-  // the other LDS buffer after them.  dY is staged by ALL 512 threads (4 channels x 1 pixel
-  // each), the X halo by the first 272 (8 channels x 1 pixel).
-  float dyr[1][4], xr[1][8];
+  // staging registers: HALF a tile (one output row of 32 pixels + its share of the halo) is issued
+  // before two k-steps (54 MFMAs per wave, ~1.7 us per SIMD pair) and committed to the other LDS
+  // buffer after them.  With a quarter tile per k-step the kernel was latency bound: staging time
+  // and MFMA time simply added up (timing-only builds: 0.26-0.35 ms + 0.6-0.7 ms = 1.0-1.2 ms).
+  // dY: 2 tasks (4 channels x 1 pixel) per thread; X halo: 640 tasks (8 channels x 1 pixel).
+  constexpr int XHALF = NXP * 8 / 2;   // 640
+  float dyr[2][4], xr[2][8];
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};  // bias-gradient partials of this thread's 4 channels
   const bool do_db = a.db != nullptr && cib == 0 && SUBPIX != 1;
-  auto issue = [&](int tile, int ks, float (&dq)[4], float (&xq)[8]) __attribute__((always_inline)) {
+  auto issue = [&](int tile, int hf) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int oy0 = ty * 2, ox0 = tx * PW;
-    {
-      const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels
-      const int oy = oy0 + (ks >> 1), ox = ox0 + 16 * (ks & 1) + pixl;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels, x-half i
+      const int oy = oy0 + hf, ox = ox0 + 16 * i + pixl;
       const bool ok = oy < a.Hout && ox < a.Wout;
       const size_t pixoff = SUBPIX == 1 ? (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px
                                         : (size_t)oy * a.Wout + ox;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int co = cob * 128 + quad * 4 + j;
-        dq[j] = (ok && co < a.Cout) ? a.dy[((size_t)n * dych + (co - (SUBPIX == 1 ? par * a.creal : 0))) * out_plane + pixoff]
-                                    : 0.f;
+        dyr[i][j] = (ok && co < a.Cout)
+                        ? a.dy[((size_t)n * dych + (co - (SUBPIX == 1 ? par * a.creal : 0))) * out_plane + pixoff]
+                        : 0.f;
       }
     }
-    if (tid < XQ) {
-      const int t2 = ks * XQ + tid;
-      const int oct = t2 / NXP, pix = t2 - oct * NXP;
-      const int rr = pix / XW, cc = pix - rr * XW;
-      int si = -1;
-      if (cc < XWV) {
-        if (SUBPIX == 2) {  // space-to-depth gather: low-res halo pixel (vy,vx) -> x[2vy+py][2vx+px]
-          const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
-          if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
-            si = (2 * vy + py) * a.Win + 2 * vx + px;
-        } else {
-          si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
-        }
-      }
-      const int xch = SUBPIX == 2 ? a.creal : a.Cin;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ci = cib * 64 + oct * 8 + j;
-        xq[j] = (si >= 0 && ci < a.Cin)
-                    ? a.x[((size_t)n * xch + (ci - (SUBPIX == 2 ? par * a.creal : 0))) * in_plane + si]
-                    : 0.f;
+    for (int i = 0; i < 2; ++i) {
+      const int tt = tid + i * 512;
+      if (tt < XHALF) {
+        const int t2 = hf * XHALF + tt;
+        const int oct = t2 / NXP, pix = t2 - oct * NXP;
+        const int rr = pix / XW, cc = pix - rr * XW;
+        int si = -1;
+        if (cc < XWV) {
+          if (SUBPIX == 2) {  // space-to-depth gather: low-res halo pixel (vy,vx) -> x[2vy+py][2vx+px]
+            const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
+            if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
+              si = (2 * vy + py) * a.Win + 2 * vx + px;
+          } else {
+            si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+          }
+        }
+        const int xch = SUBPIX == 2 ? a.creal : a.Cin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = cib * 64 + oct * 8 + j;
+          xr[i][j] = (si >= 0 && ci < a.Cin)
+                         ? a.x[((size_t)n * xch + (ci - (SUBPIX == 2 ? par * a.creal : 0))) * in_plane + si]
+                         : 0.f;
+        }
       }
     }
   };
-  auto commit = [&](int buf, int ks, const float (&dq)[4], const float (&xq)[8]) __attribute__((always_inline)) {
+  auto commit = [&](int buf, int hf) __attribute__((always_inline)) {
     unsigned char* base = smem + buf * BUF;
-    {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
       const int pixl = tid & 15, quad = tid >> 4;
       typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
       bf16x4v hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const __bf16 hb = (__bf16)dq[j];
+        const __bf16 hb = (__bf16)dyr[i][j];
         hi[j] = hb;
-        lo[j] = (__bf16)(dq[j] - (float)hb);
+        lo[j] = (__bf16)(dyr[i][j] - (float)hb);
       }
+      const int ks = 2 * hf + i;
       const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
       *reinterpret_cast<bf16x4v*>(base + off) = hi;
       if (NTERMS == 3) *reinterpret_cast<bf16x4v*>(base + DPART + off) = lo;
       if (do_db) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dbs[j] += dq[j];
+        for (int j = 0; j < 4; ++j) dbs[j] += dyr[i][j];
       }
     }
-    if (tid < XQ) {
-      const int t2 = ks * XQ + tid;
-      const int oct = t2 / NXP, pix = t2 - oct * NXP;
-      bf16x8 hi, lo;
-      split8(xq, hi, lo);
-      const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
-      *reinterpret_cast<bf16x8*>(base + off) = hi;
-      if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + XPART + off) = lo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tt = tid + i * 512;
+      if (tt < XHALF) {
+        const int t2 = hf * XHALF + tt;
+        const int oct = t2 / NXP, pix = t2 - oct * NXP;
+        bf16x8 hi, lo;
+        split8(xr[i], hi, lo);
+        const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
+        *reinterpret_cast<bf16x8*>(base + off) = hi;
+        if (NTERMS == 3) *reinterpret_cast<bf16x8*>(base + XPART + off) = lo;
+      }
     }
   };
   // PARC = compile-time parity (sub-pixel form) so every tap index / swizzle offset is static
@@ -535,9 +550,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   int tile = blockIdx.y;
   if (tile < a.ntiles) {
 #pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {
-      issue(tile, ks, dyr[0], xr[0]);
-      commit(0, ks, dyr[0], xr[0]);
+    for (int hf = 0; hf < 2; ++hf) {
+      issue(tile, hf);
+      commit(0, hf);
     }
   }
   __syncthreads();
@@ -546,11 +561,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
     const int next = tile + gridDim.y;
     const bool has_next = next < a.ntiles;
     const unsigned char* base = smem + cur * BUF;
+#ifndef EOVAE_WABL
+#define EOVAE_WABL 0
+#endif
 #pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {
-      if (has_next) issue(next, ks, dyr[0], xr[0]);
-      compute(base, ks);
-      if (has_next) commit(cur ^ 1, ks, dyr[0], xr[0]);
+    for (int hf = 0; hf < 2; ++hf) {
+      if (!(EOVAE_WABL & 1)) if (has_next) issue(next, hf);
+#pragma unroll 1
+      for (int sub = 0; sub < 2; ++sub)
+        if (!(EOVAE_WABL & 4)) compute(base, 2 * hf + sub);
+      if (!(EOVAE_WABL & 2)) if (has_next) commit(cur ^ 1, hf);
     }
     __syncthreads();
     cur ^= 1;
