@@ -342,8 +342,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 // 8-byte (dY) / 16-byte (X) channel groups of row p are XOR-swizzled by (p>>1): writes become
 // conflict free and a row stays a permutation of itself, so reads stay conflict free too; the
 // swizzled per-lane read offsets are loop-invariant registers.  Pixel tiles of 2 x 32 are double
-// buffered in LDS; the next tile is loaded one k-step (16 pixels) at a time behind the current
-// k-step's 27 MFMAs.
+// buffered in LDS; the next tile is loaded half a tile (one 32-pixel output row) at a time behind
+// two k-steps (54 MFMAs per wave).
 // ---------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -418,8 +418,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
 
   // staging registers: HALF a tile (one output row of 32 pixels + its share of the halo) is issued
   // before two k-steps (54 MFMAs per wave, ~1.7 us per SIMD pair) and committed to the other LDS
-  // buffer after them.  With a quarter tile per k-step the kernel was latency bound: staging time
-  // and MFMA time simply added up (timing-only builds: 0.26-0.35 ms + 0.6-0.7 ms = 1.0-1.2 ms).
+  // buffer after them.  Timing-only builds (EOVAE_WABL) show staging and MFMA time adding up
+  // (0.26-0.35 ms + 0.6-0.7 ms = 1.0-1.2 ms); doubling the prefetch distance from one k-step to two
+  // measured +0..3 % on the same box, so load LATENCY is not what serialises them.
   // dY: 2 tasks (4 channels x 1 pixel) per thread; X halo: 640 tasks (8 channels x 1 pixel).
   constexpr int XHALF = NXP * 8 / 2;   // 640
   float dyr[2][4], xr[2][8];

@@ -432,11 +432,26 @@ class EOFluxVAE(nn.Module):
     def decode_raw(self, z, wvs):  # :431-438
         return self.decoder(z, wvs)
 
-    def forward(self, x, wvs, sample_posterior=True, noise=None):  # :447-478
+    def _apply_scale(self, z, scale):  # :520-531 -- new size rounded to a multiple of the 2x2 packing
+        h, w = z.shape[-2:]
+        sy, sx = scale if isinstance(scale, (tuple, list)) else (scale, scale)
+        size = (round(h * sy / 2) * 2, round(w * sx / 2) * 2)
+        return F.interpolate(z, size=size, mode='bilinear', align_corners=False)
+
+    def forward(self, x, wvs, sample_posterior=True, scale=None, angle=None, noise=None):  # :447-478
         posterior = self.encode(x, wvs)
         z = posterior.sample(noise) if sample_posterior else posterior.mode()
+        if scale is not None:  # EQ-VAE latent transforms (:456-460)
+            z = self._apply_scale(z, scale)
+        if angle is not None:
+            z = torch.rot90(z, k=angle, dims=[-1, -2])
         zn = self._normalize_latent(pixel_unshuffle2(z))
         return self.decode(zn, wvs), posterior
+
+    @staticmethod
+    def eqvae_target(images, size, angle=None):  # training_step :612-627 (no_grad in the reference)
+        t = F.interpolate(images, size=size, mode='area')
+        return t if angle is None else torch.rot90(t, k=angle, dims=[-1, -2])
 
     @torch.no_grad()
     def reconstruct(self, x, wvs):  # :724-728
@@ -484,6 +499,44 @@ TINY = dict(ch=32, ch_mult=(1, 2, 4, 4), nrb=1, z=32, res=64, wv_planes=64, num_
 def charbonnier(pred, target, eps=1e-3):  # consistency_loss.py:12-21
     d = pred - target
     return torch.mean(torch.sqrt(d * d + eps * eps))
+
+
+def sam_loss(pred, target, eps=1e-8):  # consistency_loss.py:186-209 -- mean(1 - cos) over pixels
+    dot = (pred * target).sum(1)
+    den = pred.norm(dim=1) * target.norm(dim=1) + eps
+    return (1.0 - dot / den).mean()
+
+
+def gradient_difference_loss(pred, target, alpha=1.0):  # consistency_loss.py:243-269
+    def mag(t, axis):
+        a = t[:, :, 1:, :] - t[:, :, :-1, :] if axis == 2 else t[:, :, :, 1:] - t[:, :, :, :-1]
+        return a.abs()
+    ly = (mag(pred, 2) - mag(target, 2)).abs().pow(alpha)
+    lx = (mag(pred, 3) - mag(target, 3)).abs().pow(alpha)
+    return lx.mean() + ly.mean()
+
+
+def _patch_spectrum(x, patch_factor):  # ffl.py:36-57 -- non-overlapping patches, ortho 2-D FFT
+    x = x.float()
+    b, c, h, w = x.shape
+    ph, pw = h // patch_factor, w // patch_factor
+    x = x[:, :, :ph * patch_factor, :pw * patch_factor]
+    y = x.reshape(b, c, patch_factor, ph, patch_factor, pw).permute(0, 2, 4, 1, 3, 5)
+    f = torch.fft.fft2(y.reshape(b, patch_factor * patch_factor, c, ph, pw), norm='ortho')
+    return torch.nan_to_num(torch.stack([f.real, f.imag], -1), nan=0.0, posinf=1e6, neginf=-1e6)
+
+
+def focal_frequency_loss(pred, target, alpha=1.0, patch_factor=2, log_matrix=True,
+                         batch_matrix=True):  # ffl.py:59-102 with the flags of consistency_loss.py:388-395
+    fp, ft = _patch_spectrum(pred, patch_factor), _patch_spectrum(target, patch_factor)
+    d2 = ((fp - ft) ** 2).sum(-1)
+    m = torch.sqrt(d2 + 1e-8) ** alpha
+    if log_matrix:
+        m = torch.log1p(m)
+    top = m.max() if batch_matrix else m.flatten(3).max(-1).values[..., None, None]
+    top = torch.where(torch.isfinite(top) & (top > 0), top, torch.ones_like(top))
+    weight = (m / top).clamp(0.0, 1.0).detach()
+    return (weight * d2).mean()
 
 
 MSSSIM_BETAS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)  # consistency_loss.py:33
@@ -537,12 +590,18 @@ def msssim(pred, target, data_range=6.0, betas=MSSSIM_BETAS, sigma=1.5):
     return torch.prod(stack ** b, dim=0).mean()
 
 
-class EOConsistencyLoss(nn.Module):  # consistency_loss.py:329-483 (pixel + MS-SSIM branches)
-    def __init__(self, pixel_weight=1.0, rec_loss_type='l1', msssim_weight=0.0,
-                 msssim_start_step=0, kl_weight=0.0, **unused):
+class EOConsistencyLoss(nn.Module):  # consistency_loss.py:329-483 (all branches but the DOFA feature loss)
+    def __init__(self, pixel_weight=1.0, rec_loss_type='l1', spectral_weight=0.0, spatial_weight=0.0,
+                 freq_weight=0.0, msssim_weight=0.0, spectral_start_step=0, spatial_start_step=0,
+                 freq_start_step=0, msssim_start_step=0, patch_factor=2, ffl_alpha=1.0,
+                 kl_weight=0.0, **unused):
         super().__init__()
         self.pixel_weight, self.rec_loss_type = pixel_weight, rec_loss_type
         self.msssim_weight, self.msssim_start_step = msssim_weight, msssim_start_step
+        self.spectral_weight, self.spectral_start_step = spectral_weight, spectral_start_step
+        self.spatial_weight, self.spatial_start_step = spatial_weight, spatial_start_step
+        self.freq_weight, self.freq_start_step = freq_weight, freq_start_step
+        self.patch_factor, self.ffl_alpha = patch_factor, ffl_alpha
         self.kl_weight = kl_weight  # opt-in extension (absent in reference)
 
     def forward(self, inputs, wvs, reconstructions, global_step=0, split='train',
@@ -558,6 +617,20 @@ class EOConsistencyLoss(nn.Module):  # consistency_loss.py:329-483 (pixel + MS-S
                 raise ValueError("rec_loss_type must be 'l1' or 'char'")
             total = total + self.pixel_weight * l_rec
             logs[f'{split}/loss_rec'] = l_rec.detach()
+        if self.spectral_weight > 0 and global_step >= self.spectral_start_step:  # :423-428
+            l_sam = sam_loss(reconstructions, inputs)
+            total = total + self.spectral_weight * l_sam
+            logs[f'{split}/loss_spectral'] = l_sam.detach()
+        if self.spatial_weight > 0 and global_step >= self.spatial_start_step:  # :430-435
+            l_sp = gradient_difference_loss(reconstructions, inputs)
+            total = total + self.spatial_weight * l_sp
+            logs[f'{split}/loss_spatial'] = l_sp.detach()
+        if self.freq_weight > 0 and global_step >= self.freq_start_step:  # :437-464, 1000-step linear warm-up
+            raw = focal_frequency_loss(reconstructions, inputs, self.ffl_alpha, self.patch_factor)
+            w_now = self.freq_weight * min(1.0, max(0.0, (global_step - self.freq_start_step) / 1000))
+            total = total + raw * w_now
+            logs[f'{split}/loss_freq_raw'] = raw.detach()
+            logs[f'{split}/ffl_weight'] = torch.tensor(w_now)
         if self.msssim_weight > 0 and global_step >= self.msssim_start_step:
             l_ms = 1.0 - msssim(reconstructions, inputs)
             total = total + self.msssim_weight * l_ms
@@ -600,8 +673,12 @@ class TrainState:
                 self.opt, lambda s: lr_factor(s, wu, tot, base_lr, final_lr))
         self.global_step = 0
 
-    def step(self, loss_fn, images, wvs, noise=None):
-        recon, post = self.model(images, wvs, noise=noise)
+    def step(self, loss_fn, images, wvs, noise=None, scale=None, angle=None):
+        """scale/angle: the EQ-VAE draw of training_step (:601-627), injected instead of random."""
+        recon, post = self.model(images, wvs, noise=noise, scale=scale, angle=angle)
+        if scale is not None:
+            with torch.no_grad():
+                images = self.model.eqvae_target(images, recon.shape[-2:], angle)
         self.opt.zero_grad()
         loss, logs = loss_fn(inputs=images, wvs=wvs, reconstructions=recon,
                              global_step=self.global_step, split='train', posterior=post)

@@ -72,7 +72,7 @@ def ref_class_from_source(path, cls_name, ns):
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()   # a copy: running statistics are updated in place later
 
 
 def close(a, b, tol, what):
@@ -336,6 +336,113 @@ def full_size(R):
          keys=np.array(list(ref.state_dict().keys())))
 
 
+def extra_losses(R):
+    """SAM / gradient-difference / focal-frequency branches of EOConsistencyLoss.
+    consistency_loss.py cannot be imported as a whole (top-level torchmetrics import), so its
+    classes are executed one by one; SSIMLoss (torchmetrics, parity unpinned) is a placeholder
+    that the fixture never calls (msssim_weight = 0)."""
+    print('extra loss branches')
+    F = torch.nn.functional
+    ffl = importlib.import_module('eo_vae.models.modules.ffl')
+    src = os.path.join(REF, 'eo_vae/models/modules/consistency_loss.py')
+    ns = {'torch': torch, 'nn': torch.nn, 'F': F, 'FFL': ffl.FocalFrequencyLoss,
+          'SSIMLoss': type('SSIMLoss', (torch.nn.Module,), {})}
+    for cls in ['CharbonnierLoss', 'SAMLoss', 'GradientDifferenceLoss', 'EOConsistencyLoss']:
+        ref_class_from_source(src, cls, ns)
+    arrays = {}
+    target = hashed((2, 4, 32, 32), 900, 1.0) + 0.2
+    pred0 = target + 0.3 * hashed((2, 4, 32, 32), 901, 1.0)
+    arrays.update(pred=npy(pred0), target=npy(target))
+
+    def both(name, ref_fn, my_fn, tol=2e-6):
+        pr = pred0.clone().requires_grad_(True)
+        lr_ = ref_fn(pr, target)
+        lr_.backward()
+        pm = pred0.clone().requires_grad_(True)
+        lm = my_fn(pm, target)
+        lm.backward()
+        close(lm, lr_, tol, name)
+        assert (pm.grad - pr.grad).abs().max() <= 2e-6 * pr.grad.abs().max() + 1e-12, name + '.grad'
+        arrays[name] = np.float64(lr_.item())
+        arrays[name + '.grad'] = npy(pr.grad)
+
+    both('sam', ns['SAMLoss'](), O.sam_loss)
+    both('gdl', ns['GradientDifferenceLoss'](), O.gradient_difference_loss)
+    for pf, alpha in [(2, 1.0), (1, 1.0), (2, 0.5)]:
+        ref_ffl = ffl.FocalFrequencyLoss(loss_weight=1.0, alpha=alpha, patch_factor=pf, ave_spectrum=False,
+                                         batch_matrix=True, log_matrix=True)  # consistency_loss.py:388-395
+        both(f'ffl_pf{pf}_a{alpha}', ref_ffl,
+             lambda a, b: O.focal_frequency_loss(a, b, alpha=alpha, patch_factor=pf), tol=5e-6)
+    # the weighting logic incl. the 1000-step FFL warm-up (:437-464), half way through it
+    kw = dict(pixel_weight=1.0, rec_loss_type='char', spectral_weight=0.1, spatial_weight=0.5,
+              freq_weight=2.0, freq_start_step=6000, spatial_start_step=10, spectral_start_step=7000)
+    ref_l, my_l = ns['EOConsistencyLoss'](**kw), O.EOConsistencyLoss(**kw)
+    wvs = torch.tensor(O.WAVELENGTHS['S1RTC'] + O.WAVELENGTHS['S1RTC'])
+    for step in [5, 6500, 7200]:
+        tr, logs_r = ref_l(inputs=target, wvs=wvs, reconstructions=pred0, global_step=step, split='train')
+        tm, logs_m = my_l(inputs=target, wvs=wvs, reconstructions=pred0, global_step=step, split='train')
+        close(tm, tr, 2e-6, f'consistency.total[{step}]')
+        assert set(logs_r) == set(logs_m), (sorted(logs_r), sorted(logs_m))
+        arrays[f'total_step{step}'] = np.float64(tr.item())
+        arrays[f'logkeys_step{step}'] = np.array(sorted(logs_r))
+    save('op_losses_extra', **arrays)
+
+
+def eqvae(R):
+    """EQ-VAE branches of the train step (new_autoencoder.py:447-460, 520-531, 601-627) with the
+    random draw injected: (scale, angle) -> recon, area/rot90 target, L1 loss, gradient norms."""
+    print('EQ-VAE fixtures (tiny model, train mode)')
+    F = torch.nn.functional
+    cfg = O.model_cfg(**{**O.TINY, 'channels': 3})
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    mine = O.build_vae(cfg)
+    O.det_fill(ref, seed=23)
+    mine.load_state_dict(ref.state_dict())
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    x = O.synthetic_batch(2, 3, 64, seed=808)
+    arrays = {'x': npy(x)}
+    # anisotropic scale with an odd angle makes the reference's own target mis-shaped
+    # (interpolate to recon's size, THEN rot90), so that draw is not a valid fixture
+    for tag, scale, angle in [('a', 0.75, 1), ('b', (0.5, 0.75), 2), ('c', 0.5, None), ('d', 0.375, 3)]:
+        ref.load_state_dict(sd0), mine.load_state_dict(sd0)
+        ref.train(), mine.train()
+        torch.manual_seed(4242)
+        eps = torch.randn(2, 32, 8, 8)      # what posterior.sample() will draw (distributions.py:44-46)
+        torch.manual_seed(4242)
+        recon, post = ref.forward(x, wvs, scale=scale, angle=angle)
+        with torch.no_grad():               # new_autoencoder.py:612-617 / 623-627
+            tgt = F.interpolate(x, size=recon.shape[-2:], mode='area')
+            if angle is not None:
+                tgt = torch.rot90(tgt, k=angle, dims=[-1, -2])
+        ref.zero_grad()
+        loss = F.l1_loss(recon, tgt)
+        loss.backward()
+        rec_m, _ = mine(x, wvs, scale=scale, angle=angle, noise=eps)
+        tgt_m = mine.eqvae_target(x, rec_m.shape[-2:], angle)
+        mine.zero_grad()
+        loss_m = F.l1_loss(rec_m, tgt_m)
+        loss_m.backward()
+        close(rec_m, recon, 1e-4, f'eqvae.recon[{tag}]')
+        close(tgt_m, tgt, 1e-6, f'eqvae.target[{tag}]')
+        close(loss_m, loss, 2e-5, f'eqvae.loss[{tag}]')
+        gr = {k: p.grad.norm().item() for k, p in ref.named_parameters() if p.grad is not None}
+        gm = {k: p.grad.norm().item() for k, p in mine.named_parameters() if p.grad is not None}
+        assert gr.keys() == gm.keys()
+        for k in gr:
+            assert abs(gr[k] - gm[k]) <= 2e-3 * max(gr.values()), (k, gr[k], gm[k])
+        sc = np.array(scale if isinstance(scale, tuple) else (scale, scale), dtype=np.float64)
+        arrays.update({f'{tag}.scale': sc, f'{tag}.angle': np.int64(-1 if angle is None else angle),
+                       f'{tag}.eps': npy(eps), f'{tag}.recon': npy(recon), f'{tag}.target': npy(tgt),
+                       f'{tag}.loss': np.float64(loss.item()),
+                       f'{tag}.bn_mean': npy(ref.bn.running_mean)})
+        if tag == 'a':
+            arrays['a.grad_names'] = np.array(list(gr.keys()))
+            arrays['a.grad_norms'] = np.array(list(gr.values()), dtype=np.float64)
+    save('tiny_eqvae', **arrays)
+
+
 def running_stats():
     print('RunningStatsButFast fixture')
     ns = {'torch': torch, 'nn': torch.nn}
@@ -358,8 +465,11 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
     torch.manual_seed(0)  # dynamic_conv.py:7-8 reseeds the global RNG at import (quirk q1)
-    per_op(R)
-    whole_models(R)
-    running_stats()
-    full_size(R)
+    only = sys.argv[1:]  # e.g. `gen_golden.py extra_losses eqvae` regenerates just those groups
+    groups = [('per_op', lambda: per_op(R)), ('whole_models', lambda: whole_models(R)),
+              ('extra_losses', lambda: extra_losses(R)), ('eqvae', lambda: eqvae(R)),
+              ('running_stats', running_stats), ('full_size', lambda: full_size(R))]
+    for name, fn in groups:
+        if not only or name in only:
+            fn()
     print('all fixtures written; oracle == reference on every one of them')

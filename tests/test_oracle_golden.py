@@ -194,3 +194,59 @@ def test_msssim_properties():
     w = torch.randn(1, 2, 192, 192, generator=torch.Generator().manual_seed(8))
     val = O.msssim(z, -z.detach())
     assert val.item() == 0.0
+
+
+FFL_CASES = [(2, 1.0), (1, 1.0), (2, 0.5)]
+
+
+def test_extra_loss_branches(golden):
+    """SAM / gradient-difference / focal-frequency losses + the branch weighting."""
+    g = golden('op_losses_extra')
+    target = T(g['target'])
+    cases = [('sam', O.sam_loss), ('gdl', O.gradient_difference_loss)]
+    cases += [(f'ffl_pf{pf}_a{a}', lambda p, t, pf=pf, a=a: O.focal_frequency_loss(p, t, alpha=a, patch_factor=pf))
+              for pf, a in FFL_CASES]
+    for name, fn in cases:
+        pred = T(g['pred']).requires_grad_(True)
+        loss = fn(pred, target)
+        loss.backward()
+        assert_close(loss, g[name], 1e-5, name)
+        assert (pred.grad - T(g[name + '.grad'])).abs().max() <= 1e-5 * np.abs(g[name + '.grad']).max(), name
+    kw = dict(pixel_weight=1.0, rec_loss_type='char', spectral_weight=0.1, spatial_weight=0.5,
+              freq_weight=2.0, freq_start_step=6000, spatial_start_step=10, spectral_start_step=7000)
+    loss_fn = O.EOConsistencyLoss(**kw)
+    for step in [5, 6500, 7200]:
+        total, logs = loss_fn(inputs=target, wvs=None, reconstructions=T(g['pred']), global_step=step)
+        assert_close(total, g[f'total_step{step}'], 1e-5, f'total[{step}]')
+        assert sorted(logs) == list(g[f'logkeys_step{step}'])
+
+
+def test_eqvae_branches(golden):
+    """EQ-VAE draws of the train step: latent bilinear scale + rot90, area/rot90 target."""
+    g = golden('tiny_eqvae')
+    vae = O.build_vae(O.model_cfg(**{**O.TINY, 'channels': 3}))
+    O.det_fill(vae, seed=23)
+    sd0 = {k: v.clone() for k, v in vae.state_dict().items()}
+    x, wvs = T(g['x']), torch.tensor(O.WAVELENGTHS['S2RGB'])
+    for tag in 'abcd':
+        vae.load_state_dict(sd0)
+        vae.train()
+        sc = tuple(float(v) for v in g[f'{tag}.scale'])
+        scale = sc if sc[0] != sc[1] else sc[0]
+        angle = None if int(g[f'{tag}.angle']) < 0 else int(g[f'{tag}.angle'])
+        recon, _ = vae(x, wvs, scale=scale, angle=angle, noise=T(g[f'{tag}.eps']))
+        target = vae.eqvae_target(x, recon.shape[-2:], angle)
+        assert recon.shape == T(g[f'{tag}.recon']).shape
+        assert_close(recon, g[f'{tag}.recon'], 1e-4, tag + '.recon')
+        assert_close(target, g[f'{tag}.target'], 1e-6, tag + '.target')
+        loss = torch.nn.functional.l1_loss(recon, target)
+        assert_close(loss, g[f'{tag}.loss'], 2e-5, tag + '.loss')
+        assert_close(vae.bn.running_mean, g[f'{tag}.bn_mean'], 1e-5, tag + '.bn_mean')
+        if tag == 'a':
+            vae.zero_grad()
+            loss.backward()
+            gn = dict(zip(g['a.grad_names'], g['a.grad_norms']))
+            top = max(gn.values())
+            for k, p in vae.named_parameters():
+                if p.grad is not None:
+                    assert abs(p.grad.norm().item() - gn[k]) <= 2e-3 * top, k
