@@ -1,1 +1,2 @@
-from eo_vae_amd.losses import CharbonnierLoss, EOConsistencyLoss, SSIMLoss  # noqa: F401
+from eo_vae_amd.losses import (CharbonnierLoss, EOConsistencyLoss, GradientDifferenceLoss, SAMLoss,  # noqa: F401
+                               SSIMLoss)

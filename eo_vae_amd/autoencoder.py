@@ -12,7 +12,6 @@ import random
 from typing import Any
 
 import torch
-import torch.nn.functional as F
 from torch.optim.lr_scheduler import LambdaLR
 
 from . import ops
@@ -264,10 +263,9 @@ class EOFluxVAE(LightningModule):
         `noise` (optional, beyond the reference signature) injects the posterior noise."""
         posterior = self.encode(x, wvs)
         z = posterior.sample(noise) if sample_posterior else posterior.mode()
-        if scale is not None:
-            z = self._apply_scale(z, scale)
-        if angle is not None:
-            z = torch.rot90(z, k=angle, dims=[-1, -2])
+        if scale is not None or angle is not None:  # EQ-VAE: bilinear scale + rot90 in ONE gather kernel
+            size = self._scaled_size(z, scale) if scale is not None else z.shape[-2:]
+            z = ops.resize_rot(z, size, angle)
         z_normalized = self._normalize_spatial(z)
         if self.training and random.random() < self.latent_noise_p:
             z_normalized = self.noising(z_normalized)
@@ -291,12 +289,14 @@ class EOFluxVAE(LightningModule):
     def decode_spatial_normalized(self, z, wvs):
         return self.decode(_pack2x2(z), wvs)
 
-    def _apply_scale(self, z, scale):
+    def _scaled_size(self, z, scale):
+        """(:520-531) target size rounded to a multiple of the 2x2 latent packing."""
         h, w = z.shape[-2:]
         sy, sx = scale if isinstance(scale, (tuple, list)) else (scale, scale)
-        new_h = round(h * sy / self.ps[0]) * self.ps[0]
-        new_w = round(w * sx / self.ps[1]) * self.ps[1]
-        return F.interpolate(z, size=(new_h, new_w), mode='bilinear', align_corners=False)
+        return round(h * sy / self.ps[0]) * self.ps[0], round(w * sx / self.ps[1]) * self.ps[1]
+
+    def _apply_scale(self, z, scale):
+        return ops.resize_rot(z, self._scaled_size(z, scale), None)
 
     # ------------------------------------------------------------------ training
     def configure_optimizers(self):
@@ -335,13 +335,10 @@ class EOFluxVAE(LightningModule):
             scale = ((random.choice(scale_bins), random.choice(scale_bins)) if self.anisotropic
                      else random.choice(scale_bins))
             recon, posterior = self.forward(images, wvs, scale=scale, angle=angle, noise=noise)
-            with torch.no_grad():
-                target = torch.rot90(F.interpolate(images, size=recon.shape[-2:], mode='area'),
-                                     k=angle, dims=[-1, -2])
+            target = ops.area_rot(images, recon.shape[-2:], angle)  # area resize + rot90, one kernel
         elif random.random() < self.p_prior_s:  # prior preservation (:621-627)
             recon, posterior = self.forward(images, wvs, scale=random.choice(scale_bins), noise=noise)
-            with torch.no_grad():
-                target = F.interpolate(images, size=recon.shape[-2:], mode='area')
+            target = ops.area_rot(images, recon.shape[-2:], None)
         else:
             recon, posterior = self.forward(images, wvs, noise=noise)
 

@@ -53,11 +53,21 @@ SIGNATURES = {
     'eovae_loss_workspace_bytes': (_sz, []),
     'eovae_pixel_loss_fwd': (_i, [_p, _p, _sz, _i, _f, _p, _p, _p]),
     'eovae_pixel_loss_bwd': (_i, [_p, _p, _p, _p, _sz, _i, _f, _p]),
+    'eovae_sam_loss_fwd': (_i, [_p, _p, _i, _i, _i, _f, _p, _p, _p]),
+    'eovae_sam_loss_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    'eovae_gdl_loss_fwd': (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    'eovae_gdl_loss_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    'eovae_ffl_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'eovae_ffl_gy_elems': (_sz, [_i, _i, _i, _i, _i]),
+    'eovae_ffl_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    'eovae_ffl_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'eovae_msssim_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'eovae_msssim_fwd': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
     'eovae_msssim_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
     'eovae_running_stats_update': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_batch_prep': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _p]),
+    'eovae_resize_rot_bwd': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_area_rot': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_gradnorm_workspace_bytes': (_sz, []),
     'eovae_grad_norm': (_i, [_p, _sz, _f, _p, _p, _p]),
     'eovae_adam_step': (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _p, _f, _p]),

@@ -677,6 +677,167 @@ def charbonnier_loss(pred, target, eps=1e-3):
     return PixelLossFn.apply(pred, target, 1, eps)
 
 
+class SAMLossFn(torch.autograd.Function):
+    """mean(1 - cos(pred, target)) along the channel axis (consistency_loss.py:186-209)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, eps):
+        L.require_gpu(pred, 'sam_loss')
+        pred, target = _c(pred), _c(target)
+        if pred.shape != target.shape or pred.dim() != 4:
+            raise L.EovaeError(f'sam_loss: shapes {tuple(pred.shape)} vs {tuple(target.shape)}')
+        n, c, h, w = pred.shape
+        lib = L.load()
+        ws = workspace(lib.eovae_loss_workspace_bytes(), pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        L.check(lib.eovae_sam_loss_fwd(L.ptr(pred), L.ptr(target), n, c, h * w, eps, L.ptr(out), L.ptr(ws),
+                                       L.stream()), 'eovae_sam_loss_fwd')
+        ctx.save_for_backward(pred, target)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        n, c, h, w = pred.shape
+        dpred = torch.empty_like(pred)
+        L.check(L.load().eovae_sam_loss_bwd(L.ptr(pred), L.ptr(target), L.ptr(_c(gout)), L.ptr(dpred), n, c, h * w,
+                                            ctx.eps, L.stream()), 'eovae_sam_loss_bwd')
+        return dpred, None, None
+
+
+def sam_loss(pred, target, eps=1e-8):
+    return SAMLossFn.apply(pred, target, eps)
+
+
+class GradientDifferenceLossFn(torch.autograd.Function):
+    """GradientDifferenceLoss(alpha=1) (consistency_loss.py:243-269)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        L.require_gpu(pred, 'gdl_loss')
+        pred, target = _c(pred), _c(target)
+        if pred.shape != target.shape or pred.dim() != 4:
+            raise L.EovaeError(f'gdl_loss: shapes {tuple(pred.shape)} vs {tuple(target.shape)}')
+        n, c, h, w = pred.shape
+        lib = L.load()
+        ws = workspace(lib.eovae_loss_workspace_bytes(), pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        L.check(lib.eovae_gdl_loss_fwd(L.ptr(pred), L.ptr(target), n * c, h, w, L.ptr(out), L.ptr(ws), L.stream()),
+                'eovae_gdl_loss_fwd')
+        ctx.save_for_backward(pred, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        n, c, h, w = pred.shape
+        dpred = torch.empty_like(pred)
+        L.check(L.load().eovae_gdl_loss_bwd(L.ptr(pred), L.ptr(target), L.ptr(_c(gout)), L.ptr(dpred), n * c, h, w,
+                                            L.stream()), 'eovae_gdl_loss_bwd')
+        return dpred, None
+
+
+def gradient_difference_loss(pred, target):
+    return GradientDifferenceLossFn.apply(pred, target)
+
+
+class FocalFrequencyLossFn(torch.autograd.Function):
+    """FocalFrequencyLoss (ffl.py) with ave_spectrum=False, batch_matrix=True; the DFTs are fp32 MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, pred, target, alpha, patch_factor, log_matrix):
+        L.require_gpu(pred, 'focal_frequency_loss')
+        pred, target = _c(pred.float()), _c(target.float())
+        if pred.shape != target.shape or pred.dim() != 4:
+            raise L.EovaeError(f'focal_frequency_loss: shapes {tuple(pred.shape)} vs {tuple(target.shape)}')
+        b, c, h, w = pred.shape
+        lib = L.load()
+        nbytes = lib.eovae_ffl_workspace_bytes(b, c, h, w, patch_factor)
+        if nbytes == 0:
+            raise L.EovaeError(f'focal_frequency_loss: patch_factor {patch_factor} does not fit {h}x{w}')
+        ws = workspace(nbytes, pred.device)
+        gy = torch.empty(lib.eovae_ffl_gy_elems(b, c, h, w, patch_factor), dtype=torch.float32, device=pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        L.check(lib.eovae_ffl_fwd(L.ptr(pred), L.ptr(target), L.ptr(out), L.ptr(gy), L.ptr(ws), b, c, h, w,
+                                  patch_factor, alpha, int(log_matrix), L.stream()), 'eovae_ffl_fwd')
+        ctx.save_for_backward(gy)
+        ctx.geo = (b, c, h, w, patch_factor)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gy, = ctx.saved_tensors
+        b, c, h, w, pf = ctx.geo
+        lib = L.load()
+        ws = workspace(lib.eovae_ffl_workspace_bytes(b, c, h, w, pf), gy.device)
+        dpred = torch.empty((b, c, h, w), dtype=torch.float32, device=gy.device)
+        L.check(lib.eovae_ffl_bwd(L.ptr(gy), L.ptr(_c(gout)), L.ptr(dpred), L.ptr(ws), b, c, h, w, pf, L.stream()),
+                'eovae_ffl_bwd')
+        return dpred, None, None, None, None
+
+
+def focal_frequency_loss(pred, target, alpha=1.0, patch_factor=2, log_matrix=True):
+    return FocalFrequencyLossFn.apply(pred, target, float(alpha), int(patch_factor), bool(log_matrix))
+
+
+# ------------------------------------------------------------------------------------------
+# EQ-VAE latent transforms (new_autoencoder.py:456-460, 520-531, 612-627)
+# ------------------------------------------------------------------------------------------
+
+
+def _quarter_turns(angle):
+    """rot90(k, dims=[-1,-2]) of the reference -> quarter turns in the dims=[-2,-1] sense of the kernels."""
+    return 0 if angle is None else (4 - int(angle)) % 4
+
+
+class ResizeRotFn(torch.autograd.Function):
+    """rot90(F.interpolate(z, size, 'bilinear', align_corners=False), angle, dims=[-1,-2]) in one gather
+    kernel (the batch-preparation kernel without z-score/clamp); backward = its adjoint."""
+
+    @staticmethod
+    def forward(ctx, z, ht, wt, angle):
+        L.require_gpu(z, 'resize_rot')
+        z = _c(z)
+        n, c, hs, ws_ = z.shape
+        rot = _quarter_turns(angle)
+        hd, wd = (wt, ht) if rot & 1 else (ht, wt)
+        out = torch.empty((n, c, hd, wd), dtype=torch.float32, device=z.device)
+        L.check(L.load().eovae_batch_prep(L.ptr(z), None, None, L.ptr(out), n * c, 1, hs, ws_, ht, wt, 1.0, 0.0,
+                                          0, 0, rot, L.stream()), 'eovae_batch_prep')
+        ctx.geo = (n, c, hs, ws_, ht, wt, rot)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, hs, ws_, ht, wt, rot = ctx.geo
+        dy = _c(dy)
+        dz = torch.empty((n, c, hs, ws_), dtype=torch.float32, device=dy.device)
+        L.check(L.load().eovae_resize_rot_bwd(L.ptr(dy), L.ptr(dz), n * c, hs, ws_, ht, wt, rot, L.stream()),
+                'eovae_resize_rot_bwd')
+        return dz, None, None, None
+
+
+def resize_rot(z, size, angle=None):
+    return ResizeRotFn.apply(z, int(size[0]), int(size[1]), angle)
+
+
+@torch.no_grad()
+def area_rot(images, size, angle=None):
+    """rot90(F.interpolate(images, size, mode='area'), angle, dims=[-1,-2]); `size` is the size BEFORE the
+    rotation, exactly as the reference passes recon.shape[-2:] (new_autoencoder.py:612-617)."""
+    L.require_gpu(images, 'area_rot')
+    images = _c(images)
+    n, c, hs, ws_ = images.shape
+    ht, wt = int(size[0]), int(size[1])
+    rot = _quarter_turns(angle)
+    hd, wd = (wt, ht) if rot & 1 else (ht, wt)
+    out = torch.empty((n, c, hd, wd), dtype=torch.float32, device=images.device)
+    L.check(L.load().eovae_area_rot(L.ptr(images), L.ptr(out), n * c, hs, ws_, ht, wt, rot, L.stream()),
+            'eovae_area_rot')
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # optimiser primitives on flat buffers
 # ------------------------------------------------------------------------------------------

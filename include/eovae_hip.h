@@ -167,6 +167,28 @@ int eovae_pixel_loss_fwd(const float* pred, const float* target, size_t n, int k
 /* gout: device scalar holding d(total)/d(loss) */
 int eovae_pixel_loss_bwd(const float* pred, const float* target, const float* gout, float* dpred,
                          size_t n, int kind, float eps, void* stream);
+/* Spectral-angle loss: SAMLoss, consistency_loss.py:186-209 -- mean over pixels of 1 - cos(pred, target)
+ * along the channel axis, eps 1e-8 in the denominator.  pred/target [N][C][HW]. */
+int eovae_sam_loss_fwd(const float* pred, const float* target, int N, int C, int HW, float eps, float* out,
+                       void* ws, void* stream);
+int eovae_sam_loss_bwd(const float* pred, const float* target, const float* gout, float* dpred, int N, int C,
+                       int HW, float eps, void* stream);
+/* Gradient-difference loss: GradientDifferenceLoss(alpha=1), consistency_loss.py:243-269.
+ * pred/target [planes][H][W] (planes = N*C). */
+int eovae_gdl_loss_fwd(const float* pred, const float* target, int planes, int H, int W, float* out, void* ws,
+                       void* stream);
+int eovae_gdl_loss_bwd(const float* pred, const float* target, const float* gout, float* dpred, int planes, int H,
+                       int W, void* stream);
+/* Focal frequency loss (csrc/ffl.hip): FocalFrequencyLoss(alpha, patch_factor, ave_spectrum=False,
+ * log_matrix, batch_matrix=True), ffl.py:17-102 as built at consistency_loss.py:388-395.  The 2-D ortho DFT
+ * of the patch differences runs as fp32 MFMA GEMMs against on-device DFT tables.  gy (eovae_ffl_gy_elems
+ * floats, caller-allocated) carries conj(dL/dY) from the forward to the backward call. */
+size_t eovae_ffl_workspace_bytes(int B, int C, int H, int W, int patch_factor);
+size_t eovae_ffl_gy_elems(int B, int C, int H, int W, int patch_factor);
+int eovae_ffl_fwd(const float* pred, const float* target, float* out, float* gy, void* ws, int B, int C, int H,
+                  int W, int patch_factor, float alpha, int log_matrix, void* stream);
+int eovae_ffl_bwd(const float* gy, const float* gout, float* dpred, void* ws, int B, int C, int H, int W,
+                  int patch_factor, void* stream);
 /* bytes for the image pyramid + per-scale statistics kept between forward and backward */
 size_t eovae_msssim_workspace_bytes(int B, int C, int H, int W, int scales);
 /* out[0] = mean_b prod_s v_{s,b}^{beta_s}; ws keeps pyramid + per-image factors */
@@ -206,6 +228,19 @@ int eovae_running_stats_update(const float* z, float* state, int B, int C, int H
 int eovae_batch_prep(const float* src, const float* mean, const float* stdv, float* dst, int N, int C,
                      int Hs, int Ws, int Ht, int Wt, float lo, float hi, int hflip, int vflip, int rot,
                      void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * EQ-VAE transforms of the train step (csrc/eqvae.hip).  Forward latent transform
+ *   rot90(F.interpolate(z, size, 'bilinear', align_corners=False), k, dims=[-1,-2])
+ *   new_autoencoder.py:456-460, 520-531  = eovae_batch_prep(mean = std = NULL, lo > hi, rot = (4-k)%4);
+ * eovae_resize_rot_bwd is its adjoint (gradient w.r.t. z); eovae_area_rot builds the no-grad target
+ *   rot90(F.interpolate(images, size, mode='area'), k)   new_autoencoder.py:612-617, 623-627.
+ * rot = quarter turns in the torch.rot90(dims=[-2,-1]) sense, (Hd, Wd) = (Ht, Wt) swapped when odd.
+ * -------------------------------------------------------------------------------------- */
+int eovae_resize_rot_bwd(const float* dy, float* dx, int planes, int Hs, int Ws, int Ht, int Wt, int rot,
+                         void* stream);
+int eovae_area_rot(const float* src, float* dst, int planes, int Hs, int Ws, int Ht, int Wt, int rot,
+                   void* stream);
 
 #ifdef __cplusplus
 }
