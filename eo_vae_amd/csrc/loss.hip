@@ -8,7 +8,9 @@
 
 namespace {
 
-template <bool CHARB>
+// KIND 0 = L1, 1 = Charbonnier, 2 = squared error (F.mse_loss of the distillation step,
+// weight_distill_train.py:211-228)
+template <int KIND>
 __global__ __launch_bounds__(256) void pixel_loss_partial_kernel(const float* __restrict__ pred,
                                                                  const float* __restrict__ target,
                                                                  size_t n, float eps2,
@@ -18,7 +20,7 @@ __global__ __launch_bounds__(256) void pixel_loss_partial_kernel(const float* __
   int cnt = 0;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float d = pred[i] - target[i];
-    s += CHARB ? sqrtf(d * d + eps2) : fabsf(d);
+    s += KIND == 1 ? sqrtf(d * d + eps2) : (KIND == 2 ? d * d : fabsf(d));
     if (++cnt == 256) { acc += s; s = 0.f; cnt = 0; }
   }
   acc += s;
@@ -38,7 +40,7 @@ __global__ void loss_finalize_kernel(const double* __restrict__ part, int nparts
 }
 
 // dpred = (*gout / n) * dloss/dd
-template <bool CHARB>
+template <int KIND>
 __global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float* __restrict__ pred,
                                                              const float* __restrict__ target,
                                                              const float* __restrict__ gout,
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float* __rest
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float d = pred[i] - target[i];
     float g;
-    if (CHARB) g = d / sqrtf(d * d + eps2);
+    if (KIND == 1) g = d / sqrtf(d * d + eps2);
+    else if (KIND == 2) g = 2.f * d;
     else g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch: sign(0) = 0
     dpred[i] = gs * g;
   }
@@ -222,15 +225,18 @@ int eovae_gdl_loss_bwd(const float* pred, const float* target, const float* gout
 int eovae_pixel_loss_fwd(const float* pred, const float* target, size_t n, int kind, float eps,
                          float* out, void* ws, void* stream) {
   EOVAE_CHECK_ARG(pred && target && out && ws && n > 0, "pixel_loss_fwd: bad argument");
-  EOVAE_CHECK_ARG(kind == 0 || kind == 1, "pixel_loss_fwd: kind %d unknown", kind);
+  EOVAE_CHECK_ARG(kind >= 0 && kind <= 2, "pixel_loss_fwd: kind %d unknown", kind);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (kind == 1)
-    hipLaunchKernelGGL(pixel_loss_partial_kernel<true>, dim3(blocks), dim3(256), 0, st, pred, target,
+    hipLaunchKernelGGL(pixel_loss_partial_kernel<1>, dim3(blocks), dim3(256), 0, st, pred, target,
                        n, eps * eps, (double*)ws);
+  else if (kind == 2)
+    hipLaunchKernelGGL(pixel_loss_partial_kernel<2>, dim3(blocks), dim3(256), 0, st, pred, target,
+                       n, 0.f, (double*)ws);
   else
-    hipLaunchKernelGGL(pixel_loss_partial_kernel<false>, dim3(blocks), dim3(256), 0, st, pred,
+    hipLaunchKernelGGL(pixel_loss_partial_kernel<0>, dim3(blocks), dim3(256), 0, st, pred,
                        target, n, 0.f, (double*)ws);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, blocks,
                      1.0 / (double)n, out);
@@ -245,11 +251,15 @@ int eovae_pixel_loss_bwd(const float* pred, const float* target, const float* go
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
+  EOVAE_CHECK_ARG(kind >= 0 && kind <= 2, "pixel_loss_bwd: kind %d unknown", kind);
   if (kind == 1)
-    hipLaunchKernelGGL(pixel_loss_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, pred, target,
+    hipLaunchKernelGGL(pixel_loss_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, pred, target,
                        gout, dpred, n, eps * eps, (float)(1.0 / (double)n));
+  else if (kind == 2)
+    hipLaunchKernelGGL(pixel_loss_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, pred, target,
+                       gout, dpred, n, 0.f, (float)(1.0 / (double)n));
   else
-    hipLaunchKernelGGL(pixel_loss_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, pred, target,
+    hipLaunchKernelGGL(pixel_loss_bwd_kernel<0>, dim3(blocks), dim3(256), 0, st, pred, target,
                        gout, dpred, n, 0.f, (float)(1.0 / (double)n));
   EOVAE_CHECK_LAUNCH("eovae_pixel_loss_bwd");
   return EOVAE_OK;

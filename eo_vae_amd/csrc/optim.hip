@@ -41,15 +41,16 @@ __global__ void norm_finalize_kernel(const double* __restrict__ part, int nparts
   }
 }
 
-// torch.optim.Adam (no amsgrad, no weight decay); gradient pre-scaled by *clip_coef
+// torch.optim.Adam (no amsgrad); decay > 0 = torch.optim.AdamW's decoupled weight decay
+// (p *= 1 - lr * weight_decay before the update, weight_distill_train.py:317); gradient pre-scaled by *clip_coef
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    size_t n, float lr, float b1, float b2, float eps,
                                                    float bc1, float bc2_sqrt,
                                                    const float* __restrict__ clip_coef,
-                                                   float grad_scale) {
+                                                   float grad_scale, float decay) {
   const float cs = (clip_coef ? clip_coef[1] : 1.f) * grad_scale;
-  const float step = lr / bc1;
+  const float step = lr / bc1, keep = 1.f - lr * decay;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float gi = g[i] * cs;
     float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mi;
     v[i] = vi;
     float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= step * (mi / denom);
+    p[i] = p[i] * keep - step * (mi / denom);
   }
 }
 
@@ -92,13 +93,13 @@ int eovae_grad_norm(const float* g, size_t n, float max_norm, float* norm_out, v
 // step >= 1 is the Adam step count AFTER increment (bias corrections 1 - beta^step)
 int eovae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, int step, const float* clip, float grad_scale,
-                    void* stream) {
-  EOVAE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
+                    float weight_decay, void* stream) {
+  EOVAE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && weight_decay >= 0.f, "adam_step: bad argument");
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
-                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), clip, grad_scale);
+                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), clip, grad_scale, weight_decay);
   EOVAE_CHECK_LAUNCH("eovae_adam_step");
   return EOVAE_OK;
 }

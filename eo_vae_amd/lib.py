@@ -70,11 +70,12 @@ SIGNATURES = {
     'eovae_area_rot': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_gradnorm_workspace_bytes': (_sz, []),
     'eovae_grad_norm': (_i, [_p, _sz, _f, _p, _p, _p]),
-    'eovae_adam_step': (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _p, _f, _p]),
+    'eovae_adam_step': (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _p, _f, _f, _p]),
     'eovae_scale_inplace': (_i, [_p, _sz, _p, _f, _p]),
 }
 
 _lib = None
+ABI_VERSION = 2  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):
@@ -94,6 +95,9 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    if lib.eovae_abi_version() != ABI_VERSION:
+        raise EovaeError(f'{LIB_PATH} has C-ABI version {lib.eovae_abi_version()}, this package binds '
+                         f'version {ABI_VERSION}: rebuild with `python -m eo_vae_amd.build`')
     _lib = lib
     return lib
 

@@ -677,6 +677,10 @@ def charbonnier_loss(pred, target, eps=1e-3):
     return PixelLossFn.apply(pred, target, 1, eps)
 
 
+def mse_loss(pred, target):
+    return PixelLossFn.apply(pred, target, 2, 0.0)
+
+
 class SAMLossFn(torch.autograd.Function):
     """mean(1 - cos(pred, target)) along the channel axis (consistency_loss.py:186-209)."""
 
@@ -852,9 +856,9 @@ def grad_norm(flat_grad: torch.Tensor, max_norm: float, out: torch.Tensor) -> to
     return out
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, clip=None, grad_scale=1.0):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, clip=None, grad_scale=1.0, weight_decay=0.0):
     L.check(L.load().eovae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1,
-                                     beta2, eps, step, L.ptr(clip), grad_scale, L.stream()),
+                                     beta2, eps, step, L.ptr(clip), grad_scale, weight_decay, L.stream()),
             'eovae_adam_step')
 
 

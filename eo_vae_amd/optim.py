@@ -46,13 +46,15 @@ class FlatParams:
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (no amsgrad / weight decay) in one HIP launch over the flat
+    """torch.optim.Adam / AdamW semantics (no amsgrad) in one HIP launch over the flat
     buffer; clip_grad_norm() folds the clip coefficient into that launch (device side, no host
     synchronisation)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """weight_decay > 0 gives torch.optim.AdamW's DECOUPLED decay (the distillation step's optimiser,
+        weight_distill_train.py:317); torch.optim.Adam's L2-in-gradient decay is not offered."""
         params = list(params)
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise ValueError('FusedAdam supports a single parameter group')
         self.flat = FlatParams(self.param_groups[0]['params'])
@@ -86,7 +88,8 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = group['betas']
         ops.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, float(group['lr']),
                       b1, b2, group['eps'], self.step_count,
-                      clip=self._norm if self._clip_pending else None, grad_scale=self.grad_scale)
+                      clip=self._norm if self._clip_pending else None, grad_scale=self.grad_scale,
+                      weight_decay=float(group.get('weight_decay', 0.0)))
         self._clip_pending = False
         for st in self.state.values():
             st['step'] += 1

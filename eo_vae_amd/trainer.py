@@ -27,13 +27,14 @@ class Trainer:
                  limit_val_batches=None, log_every_n_steps: int = 50, default_root_dir: str | None = None,
                  callbacks=None, logger=None, accelerator: str = 'gpu', devices=None,
                  precision='32-true', strategy: str | None = None, bucket_mb: float = 48.0,
-                 enable_checkpointing: bool = True, **ignored):
+                 enable_checkpointing: bool = True, val_check_interval: int | None = None, **ignored):
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.log_every_n_steps = max(1, int(log_every_n_steps))
         self.default_root_dir = default_root_dir
         self.enable_checkpointing = enable_checkpointing and default_root_dir is not None
         self.bucket_mb = bucket_mb
+        self.val_check_interval = val_check_interval  # validate every N training steps (None: per epoch)
         self.precision = precision  # parity path is fp32 storage; AMP ('16-mixed') is not emulated
         self.rank, self.world, self.local_rank = 0, 1, 0
         self.reducer = None
@@ -82,8 +83,12 @@ class Trainer:
         conf = model.configure_optimizers()
         if isinstance(conf, tuple):
             optimizers, sched_cfgs = conf
+        elif isinstance(conf, dict):  # {'optimizer': ..., 'lr_scheduler': {...}} (weight_distill_train.py:327-330)
+            optimizers = [conf['optimizer']]
+            sched_cfgs = [conf['lr_scheduler']] if conf.get('lr_scheduler') is not None else []
         else:
             optimizers, sched_cfgs = (conf if isinstance(conf, (list, tuple)) else [conf]), []
+        automatic = bool(getattr(model, 'automatic_optimization', False))
         schedulers = [s['scheduler'] if isinstance(s, dict) else s for s in sched_cfgs]
         model.attach(self, optimizers, schedulers)
         flat = getattr(optimizers[0], 'flat', None)
@@ -105,7 +110,15 @@ class Trainer:
                 if self.world > 1:  # DDP broadcast_buffers=True semantics
                     for b in buffers:
                         dist.broadcast(b, src=0)
-                model.training_step(batch, i)
+                if automatic:  # Lightning's automatic optimisation: one optimiser, scheduler per step
+                    optimizers[0].zero_grad()
+                    loss = model.training_step(batch, i)
+                    model.manual_backward(loss)
+                    optimizers[0].step()
+                    for sch in schedulers:
+                        sch.step()
+                else:
+                    model.training_step(batch, i)
                 model._global_step += 1
                 if model._global_step % self.log_every_n_steps == 0:
                     row = self._flush(model._global_step)
@@ -115,6 +128,8 @@ class Trainer:
                               flush=True)
                 else:
                     self._pending = {}
+                if self.val_check_interval and model._global_step % self.val_check_interval == 0:
+                    self.validate(model, val_loader)
                 if self.max_steps > 0 and model._global_step >= self.max_steps:
                     done = True
                     break

@@ -157,7 +157,8 @@ int eovae_latent_inv(const float* src, float* dst, const float* run_mean, const 
 
 /* ----------------------------------------------------------------------------------------
  * Losses (csrc/loss.hip, csrc/msssim.hip): EOConsistencyLoss   consistency_loss.py:399-483
- *   kind 0 = F.l1_loss (:418), kind 1 = CharbonnierLoss eps (:12-21)
+ *   kind 0 = F.l1_loss (:418), kind 1 = CharbonnierLoss eps (:12-21),
+ *   kind 2 = F.mse_loss (the Stage-1 distillation step, weight_distill_train.py:211-228)
  *   MS-SSIM: torchmetrics MultiScaleStructuralSimilarityIndexMeasure(data_range=6,
  *            gaussian sigma 1.5 => 11 taps, 5 betas, normalize='relu')   consistency_loss.py:24-37
  * -------------------------------------------------------------------------------------- */
@@ -208,9 +209,10 @@ size_t eovae_gradnorm_workspace_bytes(void);
 int eovae_grad_norm(const float* g, size_t n, float max_norm, float* norm_out, void* ws,
                     void* stream);
 /* step = Adam step count after increment; clip (may be NULL) = norm_out of eovae_grad_norm */
+/* weight_decay > 0: decoupled (torch.optim.AdamW, weight_distill_train.py:317); 0: torch.optim.Adam */
 int eovae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, int step, const float* clip, float grad_scale,
-                    void* stream);
+                    float weight_decay, void* stream);
 int eovae_scale_inplace(float* g, size_t n, const float* clip, float s, void* stream);
 
 /* ----------------------------------------------------------------------------------------

@@ -229,6 +229,8 @@ class DynamicConv(nn.Module):  # dynamic_conv.py:369-535 (transformer generator 
         w = weight.view(wvs.numel(), k, k, self.embed_dim).permute(3, 0, 1, 2)  # [E,C,k,k]
         return w * self.scaler, bias.view(self.embed_dim) * self.scaler
 
+    get_distillation_weight = generate  # dynamic_conv.py:471-497: same weight and bias as forward
+
     def forward(self, x, wvs):
         w, b = self.generate(wvs)
         return F.conv2d(x, w, b, stride=self.stride, padding=self.padding)
@@ -251,6 +253,10 @@ class DynamicConv_decoder(nn.Module):  # dynamic_conv.py:538-710
         w = weight.view(wvs.numel(), k, k, self.embed_dim).permute(0, 3, 1, 2)  # [C,E,k,k]
         # bias is scaled TWICE in forward (dynamic_conv.py:692-697)
         return w * self.scaler, bias.squeeze() * self.scaler * self.scaler
+
+    def get_distillation_weight(self, wvs):  # dynamic_conv.py:638-664: the bias is scaled ONCE here
+        w, b = self.generate(wvs)
+        return w, b / self.scaler
 
     def forward(self, x, wvs):
         w, b = self.generate(wvs)
@@ -692,6 +698,53 @@ class TrainState:
             self.sched.step()
         self.global_step += 1
         return loss.detach(), logs, gnorm
+
+
+# --------------------------------------------------------------------------
+# Stage-1 weight distillation  (weight_distill_train.py:146-331)
+# --------------------------------------------------------------------------
+
+
+class DistillState:
+    """Data-free fit of the two dynamic layers to a teacher's RGB conv_in / conv_out kernels:
+    MSE(weight) + MSE(bias), AdamW(lr, weight_decay 1e-5) over conv_in + conv_out parameters,
+    CosineAnnealingLR(T_max = max_steps, eta_min = lr / 100) stepped every iteration."""
+
+    def __init__(self, encoder, decoder, teacher, rgb_wavelengths=(0.665, 0.560, 0.490), lr=1e-4,
+                 max_steps=5000, weight_loss_scale=1.0, bias_loss_scale=1.0):
+        self.encoder, self.decoder, self.teacher = encoder, decoder, teacher
+        self.wvs = torch.tensor(rgb_wavelengths, dtype=torch.float32)
+        self.w_scale, self.b_scale = weight_loss_scale, bias_loss_scale
+        params = list(encoder.conv_in.parameters()) + list(decoder.conv_out.parameters())  # :306-312
+        self.opt = torch.optim.AdamW(params, lr=lr, weight_decay=1e-5)
+        self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=max_steps, eta_min=lr * 0.01)
+
+    def loss(self):  # compute_distillation_loss, :190-264
+        logs, total = {}, torch.tensor(0.0)
+        for tag, layer in (('enc', self.encoder.conv_in), ('dec', self.decoder.conv_out)):
+            w, b = layer.get_distillation_weight(self.wvs)
+            tw, tb = self.teacher[f'{tag}oder_weight'], self.teacher[f'{tag}oder_bias']
+            lw = F.mse_loss(w, tw)
+            total = total + lw * self.w_scale
+            logs[f'{tag}_weight_loss'] = lw
+            if b is not None and tb is not None:
+                lb = F.mse_loss(b, tb)
+                total = total + lb * self.b_scale
+                logs[f'{tag}_bias_loss'] = lb
+            with torch.no_grad():
+                logs[f'{tag}_weight_mae'] = F.l1_loss(w, tw)
+                logs[f'{tag}_weight_max_err'] = (w - tw).abs().max()
+        logs['total_loss'] = total
+        return total, logs
+
+    def step(self):
+        loss, logs = self.loss()
+        self.opt.zero_grad()
+        loss.backward()
+        lr = self.opt.param_groups[0]['lr']
+        self.opt.step()
+        self.sched.step()
+        return loss.detach(), {k: v.detach() for k, v in logs.items()}, lr
 
 
 # --------------------------------------------------------------------------

@@ -443,6 +443,69 @@ def eqvae(R):
     save('tiny_eqvae', **arrays)
 
 
+def distill(R):
+    """Stage-1 weight distillation: the reference's DistillationModule
+    (weight_distill_train.py:146-331, executed class by class: the script's top-level imports need
+    hydra / lightning) driven the way Lightning's automatic optimisation drives it."""
+    print('distillation fixture (tiny dynamic layers)')
+    import dataclasses
+
+    class LightningStandIn(torch.nn.Module):   # the three members the module touches
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return torch.device('cpu')
+
+    src = os.path.join(REF, 'weight_distill_train.py')
+    ns = {'torch': torch, 'nn': torch.nn, 'F': torch.nn.functional, 'Tensor': torch.Tensor,
+          'dataclass': dataclasses.dataclass, 'LightningModule': LightningStandIn}
+    DistillConfig = ref_class_from_source(src, 'DistillConfig', ns)
+    Module = ref_class_from_source(src, 'DistillationModule', ns)
+    cfg = O.model_cfg(**{**O.TINY, 'channels': 3})
+    enc_r, dec_r = R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder'])
+    holder = torch.nn.ModuleDict({'encoder': enc_r, 'decoder': dec_r})
+    O.det_fill(holder, seed=41)
+    enc_m, dec_m = O.Encoder(**cfg['encoder']), O.Decoder(**cfg['decoder'])
+    enc_m.load_state_dict(enc_r.state_dict()), dec_m.load_state_dict(dec_r.state_dict())
+    teacher = {'encoder_weight': hashed((32, 3, 3, 3), 950, 0.15), 'encoder_bias': hashed((32,), 951, 0.05),
+               'decoder_weight': hashed((3, 32, 3, 3), 952, 0.15), 'decoder_bias': hashed((3,), 953, 0.05)}
+    dcfg = DistillConfig(max_steps=10, lr=1e-3)
+    ref = Module(enc_r, dec_r, {k: v.clone() for k, v in teacher.items()}, dcfg)
+    conf = ref.configure_optimizers()
+    opt, sch = conf['optimizer'], conf['lr_scheduler']['scheduler']
+    assert conf['lr_scheduler']['interval'] == 'step'
+    mine = O.DistillState(enc_m, dec_m, teacher, rgb_wavelengths=dcfg.rgb_wavelengths, lr=1e-3, max_steps=10)
+    arrays = {k: npy(v) for k, v in teacher.items()}
+    arrays['rgb_wavelengths'] = np.array(dcfg.rgb_wavelengths, dtype=np.float64)
+    for step in range(4):
+        loss, logs = ref.compute_distillation_loss()
+        opt.zero_grad()
+        loss.backward()
+        lr = opt.param_groups[0]['lr']
+        opt.step()
+        sch.step()
+        loss_m, logs_m, lr_m = mine.step()
+        close(loss_m, loss, 1e-5, f'distill.loss[{step}]')
+        assert abs(lr - lr_m) < 1e-12 and set(logs) == set(logs_m)
+        for k in logs:
+            close(logs_m[k], logs[k], 1e-5, f'distill.{k}[{step}]')
+            arrays[f'step{step}.{k}'] = np.float64(logs[k].item())
+        arrays[f'step{step}.lr'] = np.float64(lr)
+    with torch.no_grad():
+        w, b = enc_r.conv_in.get_distillation_weight(ref.rgb_wvs)
+        arrays['final.enc_w'], arrays['final.enc_b'] = npy(w), npy(b)
+        w, b = dec_r.conv_out.get_distillation_weight(ref.rgb_wvs)
+        arrays['final.dec_w'], arrays['final.dec_b'] = npy(w), npy(b)
+        wm, bm = enc_m.conv_in.get_distillation_weight(mine.wvs)
+        close(wm, arrays['final.enc_w'], 1e-3, 'distill.final.enc_w')   # AdamW: lr-sized steps on round-off
+        wm, bm = dec_m.conv_out.get_distillation_weight(mine.wvs)
+        close(bm, arrays['final.dec_b'], 1e-3, 'distill.final.dec_b')
+    arrays['logkeys'] = np.array(sorted(logs))
+    save('distill_steps', **arrays)
+
+
 def running_stats():
     print('RunningStatsButFast fixture')
     ns = {'torch': torch, 'nn': torch.nn}
@@ -468,6 +531,7 @@ if __name__ == '__main__':
     only = sys.argv[1:]  # e.g. `gen_golden.py extra_losses eqvae` regenerates just those groups
     groups = [('per_op', lambda: per_op(R)), ('whole_models', lambda: whole_models(R)),
               ('extra_losses', lambda: extra_losses(R)), ('eqvae', lambda: eqvae(R)),
+              ('distill', lambda: distill(R)),
               ('running_stats', running_stats), ('full_size', lambda: full_size(R))]
     for name, fn in groups:
         if not only or name in only:
