@@ -158,11 +158,18 @@ def main():
         driver.step(batches[i % nb], i)
     sync()
     ops.CONV3X3_TIMER = ops.KernelTimer()
+    # per-step HIP events on the compute stream (SURVEY 8d timing protocol: median and p10/p90
+    # beside the barrier-bracketed wall time that `value` is computed from)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = driver.step(batches[i % nb], i)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pick = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]  # noqa: E731
     timer, ops.CONV3X3_TIMER = ops.CONV3X3_TIMER, None
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -215,6 +222,7 @@ def main():
                          'algorithmic_bytes_per_launch': round(timer.bytes_total() / max(k_n, 1)),
                          'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
+            'step_ms_events': {'median': round(pick(0.5), 3), 'p10': round(pick(0.1), 3), 'p90': round(pick(0.9), 3)},
             'step_flops_tflops': round(f_img * ips / world / 1e12, 2),
             'hbm_roofline_frac': round(ips / world / r_hbm, 4),
             'final_loss': final_loss,

@@ -19,12 +19,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: str | None = None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local)."""
+def init_distributed(backend: str | None = None, force: bool = False):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local).
+    `force` also initialises a world of 1 (the single-GPU RCCL rehearsal in tests/test_gpu_dp.py)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:  # EOVAE_DIST_BACKEND=gloo: single-GPU rehearsal of the N>1 path
@@ -39,9 +40,11 @@ def init_distributed(backend: str | None = None):
 
 
 class BucketedGradReducer:
-    def __init__(self, flat, group=None, bucket_mb: float = 48.0):
+    def __init__(self, flat, group=None, bucket_mb: float = 48.0, force: bool = False):
+        """`force` keeps the hooks and collectives even in a world of 1 (RCCL rehearsal on one GPU)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'
         cap = int(bucket_mb * (1 << 20) / flat.grad.element_size())
         # buckets = contiguous [start, end) ranges of the flat gradient, built back to front
@@ -60,14 +63,14 @@ class BucketedGradReducer:
         self.launched = [False] * len(self.buckets)
         self.works = []
         self.handles = []
-        if self.world > 1:
+        if self.active:
             for p in flat.params:
                 if p.requires_grad:
                     self.handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # ---- start-of-training synchronisation (DDP constructor broadcast, C1) ----
     def broadcast_parameters(self, buffers=()):
-        if self.world == 1:
+        if not self.active:
             return
         dist.broadcast(self.flat.data, src=0, group=self.group)
         for b in buffers:
@@ -89,7 +92,7 @@ class BucketedGradReducer:
     def finish(self):
         """Call after backward: launches buckets whose parameters received no gradient, waits
         for every collective, leaves the AVERAGED gradient in flat.grad."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in range(len(self.buckets)):
             if not self.launched[b]:
