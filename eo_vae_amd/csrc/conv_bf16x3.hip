@@ -83,8 +83,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   constexpr int XTASKS = NPX * 2;               // (pixel, 8-channel octet)
   constexpr int XPT = (XTASKS + NTHR - 1) / NTHR;
   constexpr int WPT = 1536 / NTHR;              // 16-byte weight units per thread and phase
-  constexpr int OFF_XLO = XBYTES, OFF_W = 2 * XBYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XBYTES + 2 * WPHASE];
+#ifndef EOVAE_XDB8
+#define EOVAE_XDB8 0
+#endif
+  // the 16-row tile is alone on its CU anyway (242 VGPRs => 2 waves/SIMD), so it can afford a second
+  // halo buffer: the next chunk's tile is converted and written while the current one is still being
+  // read, with no barrier pair (and no all-waves-idle section) around the write.  The 8-row tile keeps
+  // one buffer: it exists to run two blocks per CU.
+  constexpr bool XDB = TH == 16 || EOVAE_XDB8;
+  constexpr int XSET = 2 * XBYTES;              // hi + lo image of one halo tile
+  constexpr int OFF_XLO = XBYTES, OFF_W = (XDB ? 2 : 1) * XSET;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_W + 2 * WPHASE];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -120,9 +129,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
   float xr[XPT][8];
   f32x4 wr[WPT];
 
-  // chunk-invariant source offsets of this thread's halo tasks (index math hoisted out of the
-  // K loop: it cost ~10 % of the kernel when recomputed per chunk)
-  int xsi[XPT];
+  // chunk-invariant element offset of this thread's halo tasks inside image n (index math hoisted out
+  // of the K loop), including the octet's 8-channel stride, and whether the pixel exists at all.
+  // The loads themselves are UNCONDITIONAL (a padded pixel reads offset 0 and is zeroed when it is
+  // converted): predicated loads made the compiler wrap every one of them in an exec-mask branch and
+  // drain vmcnt(0) after every second one -- 12 exposed memory latencies per chunk, 23-32 % of the kernel.
+  unsigned xoff[XPT];
+  bool xok[XPT];
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int t = tid + i * NTHR;
@@ -137,7 +150,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
         si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
       }
     }
-    xsi[i] = si;
+    xok[i] = si >= 0;
+    xoff[i] = (unsigned)((t < XTASKS ? g : 0) * 8) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0);
   }
   auto load_x = [&](int c0) {
     int cbase = c0, poff = 0;
@@ -146,28 +160,41 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
       cbase = c0 - par * a.creal;
       poff = (par >> 1) * a.Win + (par & 1);
     }
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int g = (tid + i * NTHR) / NPX;
-      const int si = xsi[i];
-      const float* src = xn + (size_t)(cbase + g * 8) * in_plane + (si >= 0 ? si + poff : 0);
+    const float* cb = xn + (size_t)cbase * in_plane + poff;  // wave-uniform base of the chunk
+    if (c0 + KC <= a.Cin) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int ci = c0 + g * 8 + j;
-        xr[i][j] = (si >= 0 && ci < a.Cin) ? src[(size_t)j * in_plane] : 0.f;
+        const float* cj = cb + (size_t)j * in_plane;         // scalar base + 32-bit lane offset
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) xr[i][j] = cj[xoff[i]];
+      }
+    } else {  // ragged channel tail (only the last chunk of a layer whose Cin is not a multiple of 16)
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int g = (tid + i * NTHR) / NPX;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = c0 + g * 8 + j;
+          xr[i][j] = ci < a.Cin ? cb[(size_t)j * in_plane + xoff[i]] : 0.f;
+        }
       }
     }
   };
-  auto store_x = [&]() {
+  auto store_x = [&](int xb) {
+    unsigned char* xs = smem + (XDB ? xb * XSET : 0);
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int t = tid + i * NTHR;
       if (t < XTASKS) {
         const int g = t / NPX, pix = t - g * NPX;
         bf16x8 hi, lo;
+        if (!xok[i]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xr[i][j] = 0.f;
+        }
         split8(xr[i], hi, lo);
-        *reinterpret_cast<bf16x8*>(smem + g * (NPX * 16) + pix * 16) = hi;
-        if (NTERMS == 3) *reinterpret_cast<bf16x8*>(smem + OFF_XLO + g * (NPX * 16) + pix * 16) = lo;
+        *reinterpret_cast<bf16x8*>(xs + g * (NPX * 16) + pix * 16) = hi;
+        if (NTERMS == 3) *reinterpret_cast<bf16x8*>(xs + OFF_XLO + g * (NPX * 16) + pix * 16) = lo;
       }
     }
   };
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 
   load_x(0);
   load_w(0, win0(parity_of(0) >> 1));
-  store_x();
+  store_x(0);
   store_w(0);
   __syncthreads();
 
@@ -236,9 +263,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
       int nky = win0(parity_of(nchk) >> 1) + (p + 1 - nchk * kyn);
       load_w(nchk, nky > 2 ? 2 : nky);
     }
-    if (!(EOVAE_ABL & 2)) if (kyi == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
+    // timing-only: 8 = no global loads for the halo (stale registers re-converted), 16 = loads kept
+    // alive but no conversion / LDS write
+    if (!(EOVAE_ABL & (2 | 8))) if (kyi == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
 
     const unsigned char* wb = smem + OFF_W + buf * WPHASE;
+    const unsigned char* xb = smem + (XDB ? (chunk & 1) * XSET : 0);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       if (!row_active || kx < kx0 || kx >= kx0 + kxn) continue;  // uniform: outside the parity's support
@@ -252,10 +282,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int pix = (wrow + j + ky) * XW + r + kx;
-        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(smem + h * (NPX * 16) + pix * 16);
+        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(xb + h * (NPX * 16) + pix * 16);
         bf16x8 blo;
         if (NTERMS == 3)
-          blo = *reinterpret_cast<const bf16x8*>(smem + OFF_XLO + h * (NPX * 16) + pix * 16);
+          blo = *reinterpret_cast<const bf16x8*>(xb + OFF_XLO + h * (NPX * 16) + pix * 16);
 #if EOVAE_EXP & 1
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -275,8 +305,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 
     if (!(EOVAE_ABL & 1)) if (p + 1 < nphase) store_w(buf ^ 1);  // other buffer: last read in phase p-1, fenced below
     if (kyi == kyn - 1 && chunk + 1 < a.nchunk) {
-      if (!(EOVAE_ABL & 4)) LDS_BARRIER();  // every wave has finished reading this chunk's halo tile
-      if (!(EOVAE_ABL & 2)) store_x();
+      // one buffer: every wave must have finished reading this chunk's halo tile first; two buffers:
+      // the other one was last read in chunk - 1, a barrier ago
+      if (!XDB) if (!(EOVAE_ABL & 4)) LDS_BARRIER();
+      if (EOVAE_ABL & 16) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(xr[i][j]));
+      } else if (!(EOVAE_ABL & 2)) store_x((chunk + 1) & 1);
     }
     if (!(EOVAE_ABL & 4)) LDS_BARRIER();
   }
@@ -426,6 +463,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   float dyr[2][4], xr[2][8];
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};  // bias-gradient partials of this thread's 4 channels
   const bool do_db = a.db != nullptr && cib == 0 && SUBPIX != 1;
+  unsigned vmask = 0xf;  // bit i: dY task i valid; bit 2+i: X task i valid (set by issue*, used by commit)
   auto issue = [&](int tile, int hf) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % a.tiles_x;
@@ -475,9 +513,77 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
         }
       }
     }
+    vmask = 0xf;  // zeros already selected
+  };
+  // Fast path (every channel of the block's 128 co x 64 ci slab exists -- all layers of the model):
+  // UNCONDITIONAL loads from clamped addresses, validity kept as 4 mask bits and applied when the
+  // registers are converted.  Predicated loads (`ok ? p[i] : 0`) compile to an exec-mask branch per
+  // load plus vmcnt(0) drains between them, i.e. several fully exposed memory latencies per half tile.
+  const bool fullc = cob * 128 + 128 <= a.Cout && cib * 64 + 64 <= a.Cin;
+  const float* dyb = a.dy + (size_t)(cob * 128 - (SUBPIX == 1 ? par * a.creal : 0)) * out_plane;
+  const float* xb = a.x + (size_t)(cib * 64 - (SUBPIX == 2 ? par * a.creal : 0)) * in_plane;
+  auto issue_fast = [&](int tile, int hf) __attribute__((always_inline)) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty * 2, ox0 = tx * PW;
+    const int xch = SUBPIX == 2 ? a.creal : a.Cin;
+    const float* dyn = dyb + (size_t)n * dych * out_plane;   // wave-uniform bases
+    const float* xn = xb + (size_t)n * xch * in_plane;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pixl = tid & 15, quad = tid >> 4;
+      const int oy = oy0 + hf, ox = ox0 + 16 * i + pixl;
+      const bool ok = oy < a.Hout && ox < a.Wout;
+      const unsigned pixoff = !ok ? 0u
+                              : (SUBPIX == 1 ? (unsigned)((2 * oy + py) * (2 * a.Wout) + 2 * ox + px)
+                                             : (unsigned)(oy * a.Wout + ox));
+      m |= (ok ? 1u : 0u) << i;
+      const float* src = dyn + (size_t)(quad * 4) * out_plane + pixoff;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dyr[i][j] = src[(size_t)j * out_plane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tt = tid + i * 512;
+      const int t2 = hf * XHALF + (tt < XHALF ? tt : 0);
+      const int oct = t2 / NXP, pix = t2 - oct * NXP;
+      const int rr = pix / XW, cc = pix - rr * XW;
+      int si = -1;
+      if (cc < XWV && tt < XHALF) {
+        if (SUBPIX == 2) {
+          const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
+          if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
+            si = (2 * vy + py) * a.Win + 2 * vx + px;
+        } else {
+          si = src_index3(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+        }
+      }
+      m |= (si >= 0 ? 1u : 0u) << (2 + i);
+      const float* src = xn + (size_t)(oct * 8) * in_plane + (si >= 0 ? si : 0);
+      if (i == 0 || tid < XHALF - 512) {   // second round: 128 of the 512 threads
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = src[(size_t)j * in_plane];
+      }
+    }
+    vmask = m;
   };
   auto commit = [&](int buf, int hf) __attribute__((always_inline)) {
     unsigned char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!((vmask >> i) & 1)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dyr[i][j] = 0.f;
+      }
+      if (!((vmask >> (2 + i)) & 1)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pixl = tid & 15, quad = tid >> 4;
@@ -552,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
   if (tile < a.ntiles) {
 #pragma unroll 1
     for (int hf = 0; hf < 2; ++hf) {
-      issue(tile, hf);
+      if (fullc) issue_fast(tile, hf); else issue(tile, hf);
       commit(0, hf);
     }
   }
@@ -567,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
 #endif
 #pragma unroll 1
     for (int hf = 0; hf < 2; ++hf) {
-      if (!(EOVAE_WABL & 1)) if (has_next) issue(next, hf);
+      if (!(EOVAE_WABL & 1)) if (has_next) { if (fullc) issue_fast(next, hf); else issue(next, hf); }
 #pragma unroll 1
       for (int sub = 0; sub < 2; ++sub)
         if (!(EOVAE_WABL & 4)) compute(base, 2 * hf + sub);
