@@ -626,22 +626,35 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
     const bf16x8 ahi = tr_frag(ap + sa0, ap + sa1);
     bf16x8 alo;
     if (NTERMS == 3) alo = tr_frag(ap + DPART + sa0, ap + DPART + sa1);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    // software pipeline over the taps: the X fragments of tap t+1 are requested BEFORE tap t's three
+    // MFMAs are issued (left alone the compiler requests them after, then waits: one exposed
+    // transposed-read latency per 3 MFMAs)
+    auto tap_ok = [&](int t) { return !(SUBPIX == 2 && (((t >> 1) && PY) || ((t & 1) && PX))); };
+    auto xfrag = [&](int t, bf16x8& fhi, bf16x8& flo) __attribute__((always_inline)) {
       const int ky = SUBPIX == 1 ? PY + (t >> 1) : (SUBPIX == 2 ? 1 + (t >> 1) : t / 3);
       const int kx = SUBPIX == 1 ? PX + (t & 1) : (SUBPIX == 2 ? 1 + (t & 1) : t % 3);
-      if (SUBPIX == 2 && (((t >> 1) && PY) || ((t & 1) && PX))) continue;  // compile-time: odd axes have 1 tap
       // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8)
       const unsigned char* bp = base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64;
       const int o0 = kx == 0 ? sx0 : (kx == 1 ? sx1 : sx2);
       const int o1 = (kx == 0 ? sx4 : (kx == 1 ? sx5 : sx6)) + 4 * 64;
-      const bf16x8 bhi = tr_frag(bp + o0, bp + o1);
+      fhi = tr_frag(bp + o0, bp + o1);
+      if (NTERMS == 3) flo = tr_frag(bp + XPART + o0, bp + XPART + o1);
+    };
+    bf16x8 bhi, blo, nhi, nlo;
+    xfrag(0, bhi, blo);   // tap 0 is active for every parity
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!tap_ok(t)) continue;  // compile-time: odd axes of the space-to-depth form have 1 tap
+      int tn = t + 1;
+      while (tn < NT && !tap_ok(tn)) ++tn;
+      if (tn < NT) xfrag(tn, nhi, nlo);
       if (NTERMS == 3) {
-        const bf16x8 blo = tr_frag(bp + XPART + o0, bp + XPART + o1);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[t], 0, 0, 0);
       }
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[t], 0, 0, 0);
+      bhi = nhi;
+      blo = nlo;
     }
   };
   auto compute = [&](const unsigned char* base, int ks) __attribute__((always_inline)) {
@@ -654,34 +667,44 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_kernel(WgBArgs a) {
     }
   };
 
-  int tile = blockIdx.y;
-  if (tile < a.ntiles) {
-#pragma unroll 1
-    for (int hf = 0; hf < 2; ++hf) {
-      if (fullc) issue_fast(tile, hf); else issue(tile, hf);
-      commit(0, hf);
-    }
-  }
-  __syncthreads();
-  int cur = 0;
-  for (; tile < a.ntiles; tile += gridDim.y) {
-    const int next = tile + gridDim.y;
-    const bool has_next = next < a.ntiles;
-    const unsigned char* base = smem + cur * BUF;
+  // The tile loop is instantiated once per load path: a run-time choice between issue_fast() and
+  // issue() inside ONE loop makes the loaded registers phi nodes, and the compiler then waits for
+  // vmcnt(0) and copies them at the join -- right after issuing the loads, before the MFMAs.
 #ifndef EOVAE_WABL
 #define EOVAE_WABL 0
 #endif
+  auto run = [&](auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_t)::value;
+    auto load = [&](int tile, int hf) __attribute__((always_inline)) {
+      if constexpr (FULL) issue_fast(tile, hf); else issue(tile, hf);
+    };
+    int tile = blockIdx.y;
+    if (tile < a.ntiles) {
 #pragma unroll 1
-    for (int hf = 0; hf < 2; ++hf) {
-      if (!(EOVAE_WABL & 1)) if (has_next) { if (fullc) issue_fast(next, hf); else issue(next, hf); }
-#pragma unroll 1
-      for (int sub = 0; sub < 2; ++sub)
-        if (!(EOVAE_WABL & 4)) compute(base, 2 * hf + sub);
-      if (!(EOVAE_WABL & 2)) if (has_next) commit(cur ^ 1, hf);
+      for (int hf = 0; hf < 2; ++hf) {
+        load(tile, hf);
+        commit(0, hf);
+      }
     }
     __syncthreads();
-    cur ^= 1;
-  }
+    int cur = 0;
+    for (; tile < a.ntiles; tile += gridDim.y) {
+      const int next = tile + gridDim.y;
+      const bool has_next = next < a.ntiles;
+      const unsigned char* base = smem + cur * BUF;
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        if (!(EOVAE_WABL & 1)) if (has_next) load(next, hf);
+#pragma unroll 1
+        for (int sub = 0; sub < 2; ++sub)
+          if (!(EOVAE_WABL & 4)) compute(base, 2 * hf + sub);
+        if (!(EOVAE_WABL & 2)) if (has_next) commit(cur ^ 1, hf);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  };
+  if (fullc) run(std::true_type{}); else run(std::false_type{});
 
   if (do_db) {  // lanes 16q..16q+15 hold the same 4 channels at 16 different pixels
 #pragma unroll
