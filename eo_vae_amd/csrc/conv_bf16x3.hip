@@ -279,13 +279,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
         ahi[i] = *reinterpret_cast<const bf16x8*>(wb + off);
         if (NTERMS == 3) alo[i] = *reinterpret_cast<const bf16x8*>(wb + off + BM * KC * 2);
       }
+      // software pipeline over the pixel-row tiles: row j+1's X fragments are requested before row j's
+      // six MFMAs are issued (the compiler on its own requests them after, then waits on lgkmcnt)
+      auto xfrag = [&](int j, bf16x8& fhi, bf16x8& flo) __attribute__((always_inline)) {
+        const int pix = (wrow + j + ky) * XW + r + kx;
+        fhi = *reinterpret_cast<const bf16x8*>(xb + h * (NPX * 16) + pix * 16);
+        if (NTERMS == 3) flo = *reinterpret_cast<const bf16x8*>(xb + OFF_XLO + h * (NPX * 16) + pix * 16);
+      };
+      bf16x8 bhi, blo, nhi, nlo;
+      xfrag(0, bhi, blo);
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const int pix = (wrow + j + ky) * XW + r + kx;
-        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(xb + h * (NPX * 16) + pix * 16);
-        bf16x8 blo;
-        if (NTERMS == 3)
-          blo = *reinterpret_cast<const bf16x8*>(xb + OFF_XLO + h * (NPX * 16) + pix * 16);
+        if (j + 1 < NI) xfrag(j + 1, nhi, nlo);
 #if EOVAE_EXP & 1
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -300,6 +305,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 #if EOVAE_EXP & 1
         __builtin_amdgcn_s_setprio(0);
 #endif
+        bhi = nhi;
+        blo = nlo;
       }
     }
 

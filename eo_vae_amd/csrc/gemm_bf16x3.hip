@@ -8,6 +8,7 @@
 // weight gradient -- and the five attention contractions (layers.py:133-139).
 // 1x1 convolutions are L2/HBM-bandwidth bound at these channel counts (<= 64 flop/byte).
 #include "eovae_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -82,29 +83,44 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
   auto b_task = [&](int t, int& n, int& oct) {
     if (B_KC) { n = t >> 2; oct = t & 3; } else { n = t & (BN - 1); oct = t >> 8; }
   };
-  auto load_stage = [&](int s) {
+  // Row validity is stage-invariant: rows beyond M / N load a clamped (valid) row and are zeroed
+  // when the stage is converted.  With K a multiple of the 32-deep stage (every GEMM of the model)
+  // all loads are then UNCONDITIONAL; predicated loads compile to an exec-mask branch per load with
+  // vmcnt(0) drains in between (see conv_bf16x3.hip), exposing the memory latency over and over.
+  int am, aoct, bn_[2], boct[2];
+  a_task(tid, am, aoct);
+  const bool okm = m0 + am < g.M;
+  const long long arow = (long long)(okm ? m0 + am : g.M - 1) * g.sam;
+  bool okn[2];
+  long long brow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    b_task(tid + i * 512, bn_[i], boct[i]);
+    okn[i] = n0 + bn_[i] < g.N;
+    brow[i] = (long long)(okn[i] ? n0 + bn_[i] : g.N - 1) * g.sbn;
+  }
+  auto load_stage = [&](int s, auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULLK = decltype(full_t)::value;
     const int slab = s / stages_slab;
     const int k0 = (s - slab * stages_slab) * KS;
     const float* As_ = A + slab * g.kbA;
     const float* Bs_ = B + slab * g.kbB;
     {
-      int m, oct;
-      a_task(tid, m, oct);
-      const bool okm = m0 + m < g.M;
-      const float* p = As_ + (long long)(m0 + m) * g.sam + (long long)(k0 + oct * 8) * g.sak;
+      const float* p = As_ + arow + (long long)(k0 + aoct * 8) * g.sak;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        ar[j] = (okm && k0 + oct * 8 + j < g.K) ? p[(long long)j * g.sak] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        if (FULLK) ar[j] = p[(long long)j * g.sak];
+        else ar[j] = (k0 + aoct * 8 + j < g.K) ? p[(long long)j * g.sak] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int n, oct;
-      b_task(tid + i * 512, n, oct);
-      const bool okn = n0 + n < g.N;
-      const float* p = Bs_ + (long long)(n0 + n) * g.sbn + (long long)(k0 + oct * 8) * g.sbk;
+      const float* p = Bs_ + brow[i] + (long long)(k0 + boct[i] * 8) * g.sbk;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        br[i][j] = (okn && k0 + oct * 8 + j < g.K) ? p[(long long)j * g.sbk] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        if (FULLK) br[i][j] = p[(long long)j * g.sbk];
+        else br[i][j] = (k0 + boct[i] * 8 + j < g.K) ? p[(long long)j * g.sbk] : 0.f;
+      }
     }
   };
   auto store_stage = [&]() {
@@ -112,6 +128,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
       int m, oct;
       a_task(tid, m, oct);
       bf16x8 hi, lo;
+      if (!okm) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ar[j] = 0.f;
+      }
       split8g(ar, hi, lo);
       const int off = (oct >> 1) * (BM * 32) + m * 32 + (oct & 1) * 16;
       *reinterpret_cast<bf16x8*>(smem + off) = hi;
@@ -122,6 +142,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
       int n, oct;
       b_task(tid + i * 512, n, oct);
       bf16x8 hi, lo;
+      if (!okn[i]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) br[i][j] = 0.f;
+      }
       split8g(br[i], hi, lo);
       const int off = (oct >> 1) * (BN * 32) + n * 32 + (oct & 1) * 16;
       *reinterpret_cast<bf16x8*>(smem + OFF_B + off) = hi;
@@ -129,12 +153,14 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
     }
   };
 
-  if (s_beg < s_end) load_stage(s_beg);
+  // one instantiation of the stage loop per load path (no phi join between the loads and their use)
+  auto run = [&](auto full_t) __attribute__((always_inline)) {
+  if (s_beg < s_end) load_stage(s_beg, full_t);
   for (int s = s_beg; s < s_end; ++s) {
     __syncthreads();
     store_stage();
     __syncthreads();
-    if (s + 1 < s_end) load_stage(s + 1);
+    if (s + 1 < s_end) load_stage(s + 1, full_t);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 ahi[2], alo[2], bhi[2], blo[2];
@@ -162,6 +188,8 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
         }
     }
   }
+  };
+  if (g.K % KS == 0) run(std::true_type{}); else run(std::false_type{});
 
 #pragma unroll
   for (int i = 0; i < 2; ++i)
