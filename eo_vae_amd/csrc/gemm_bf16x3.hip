@@ -27,6 +27,7 @@ struct GemmBArgs {
   // weight gradient): k_total = kb * K, slab j of A/B starts at j*kbA / j*kbB
   int kb;
   long long kbA, kbB;
+  int vec;  // every k-contiguous operand: base, row / batch / slab strides multiples of 16 bytes
 };
 
 __device__ __forceinline__ void split8g(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -38,8 +39,11 @@ __device__ __forceinline__ void split8g(const float (&v)[8], bf16x8& hi, bf16x8&
   }
 }
 
+#ifndef EOVAE_GEMM_MINB
+#define EOVAE_GEMM_MINB 4
+#endif
 template <bool A_KC, bool B_KC, int NTERMS>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
+__global__ __launch_bounds__(512, EOVAE_GEMM_MINB) void gemm_bf16_kernel(GemmBArgs g) {
   constexpr int BM = 128, BN = 256, KS = 32;
   constexpr int A_IMG = 2 * BM * 32, B_IMG = 2 * BN * 32;  // bytes of one (hi or lo) stage image
   constexpr int OFF_ALO = A_IMG, OFF_B = 2 * A_IMG, OFF_BLO = 2 * A_IMG + B_IMG;
@@ -99,27 +103,54 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
     okn[i] = n0 + bn_[i] < g.N;
     brow[i] = (long long)(okn[i] ? n0 + bn_[i] : g.N - 1) * g.sbn;
   }
-  auto load_stage = [&](int s, auto full_t) __attribute__((always_inline)) {
-    constexpr bool FULLK = decltype(full_t)::value;
+  // MODE 0: ragged K (predicated); 1: K % 32 == 0; 2: additionally every k-contiguous operand is
+  // 16-byte aligned, so its 8 consecutive k values are two dwordx4 loads instead of eight dword loads
+  // that each touch the same cache lines again
+  // row-contiguous operands (unit row stride): 32-bit lane offset of the (clamped) row
+  const unsigned arow32 = (unsigned)(okm ? m0 + am : g.M - 1);
+  const unsigned brow32[2] = {(unsigned)(okn[0] ? n0 + bn_[0] : g.N - 1), (unsigned)(okn[1] ? n0 + bn_[1] : g.N - 1)};
+  auto load_stage = [&](int s, auto mode_t) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_t)::value;
+    constexpr bool FULLK = MODE >= 1, VEC = MODE == 2;
     const int slab = s / stages_slab;
     const int k0 = (s - slab * stages_slab) * KS;
     const float* As_ = A + slab * g.kbA;
     const float* Bs_ = B + slab * g.kbB;
-    {
-      const float* p = As_ + arow + (long long)(k0 + aoct * 8) * g.sak;
+    if constexpr (A_KC) {  // k contiguous: one per-lane address, 8 consecutive floats
+      const float* p = As_ + arow + (k0 + aoct * 8);
+      if (VEC) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (FULLK) ar[j] = p[(long long)j * g.sak];
-        else ar[j] = (k0 + aoct * 8 + j < g.K) ? p[(long long)j * g.sak] : 0.f;
+        for (int j = 0; j < 4; ++j) { ar[j] = v0[j]; ar[4 + j] = v1[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ar[j] = (FULLK || k0 + aoct * 8 + j < g.K) ? p[j] : 0.f;
       }
+    } else {  // rows contiguous: the octet is wave-uniform => scalar base per k + 32-bit lane offset
+      const int octu = __builtin_amdgcn_readfirstlane(aoct);
+      const float* pu = As_ + (long long)(k0 + octu * 8) * g.sak;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        ar[j] = (FULLK || k0 + octu * 8 + j < g.K) ? pu[(long long)j * g.sak + arow32] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float* p = Bs_ + brow[i] + (long long)(k0 + boct[i] * 8) * g.sbk;
+      if constexpr (B_KC) {
+        const float* p = Bs_ + brow[i] + (k0 + boct[i] * 8);
+        if (VEC) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (FULLK) br[i][j] = p[(long long)j * g.sbk];
-        else br[i][j] = (k0 + boct[i] * 8 + j < g.K) ? p[(long long)j * g.sbk] : 0.f;
+          for (int j = 0; j < 4; ++j) { br[i][j] = v0[j]; br[i][4 + j] = v1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) br[i][j] = (FULLK || k0 + boct[i] * 8 + j < g.K) ? p[j] : 0.f;
+        }
+      } else {
+        const int octu = __builtin_amdgcn_readfirstlane(boct[i]);
+        const float* pu = Bs_ + (long long)(k0 + octu * 8) * g.sbk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          br[i][j] = (FULLK || k0 + octu * 8 + j < g.K) ? pu[(long long)j * g.sbk + brow32[i]] : 0.f;
       }
     }
   };
@@ -163,7 +194,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
     if (s + 1 < s_end) load_stage(s + 1, full_t);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 ahi[2], alo[2], bhi[2], blo[2];
+      // B fragments one column tile at a time: 8 fewer live VGPRs than holding both (the kernel is
+      // capped at 128 VGPRs for two blocks per CU, and a spilled address is reloaded through the same
+      // in-order vmcnt queue as the operand loads)
+      bf16x8 ahi[2], alo[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int off = kk * (BM * 32) + (wm + i * 32 + r) * 32 + h * 16;
@@ -173,23 +207,24 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_kernel(GemmBArgs g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int off = kk * (BN * 32) + (wn + j * 32 + r) * 32 + h * 16;
-        bhi[j] = *reinterpret_cast<const bf16x8*>(smem + OFF_B + off);
-        if (NTERMS == 3) blo[j] = *reinterpret_cast<const bf16x8*>(smem + OFF_BLO + off);
-      }
+        const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(smem + OFF_B + off);
+        bf16x8 blo;
+        if (NTERMS == 3) blo = *reinterpret_cast<const bf16x8*>(smem + OFF_BLO + off);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int i = 0; i < 2; ++i) {
           if (NTERMS == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo, acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi, acc[i][j], 0, 0, 0);
         }
+      }
     }
   }
   };
-  if (g.K % KS == 0) run(std::true_type{}); else run(std::false_type{});
+  if (g.K % KS != 0) run(std::integral_constant<int, 0>{});
+  else if ((A_KC || B_KC) && g.vec) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 1>{});
 
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -248,6 +283,10 @@ int eovae_gemm_bf16x3(const float* A, const float* B, float* C, const float* bia
   g.kb = kb; g.kbA = kbA; g.kbB = kbB;
   dim3 grid((unsigned)(batch * ksplit * g.tiles_m * g.tiles_n));
   const bool ak = (sak == 1 && sam != 1), bk = (sbk == 1 && sbn != 1);
+  auto al16 = [](const float* p, long long row, long long bat, long long slab) {
+    return ((uintptr_t)p % 16 == 0) && row % 4 == 0 && bat % 4 == 0 && slab % 4 == 0;
+  };
+  g.vec = (!ak || al16(A, sam, batA, kbA)) && (!bk || al16(B, sbn, batB, kbB));
   if (precision == 3) launch<3>(g, grid, (hipStream_t)stream, ak, bk);
   else launch<1>(g, grid, (hipStream_t)stream, ak, bk);
   EOVAE_CHECK_LAUNCH("eovae_gemm_bf16x3");
