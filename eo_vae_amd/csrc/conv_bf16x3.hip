@@ -44,6 +44,7 @@ struct ConvBArgs {
   //   subpix 3 (forward):  K = 4*creal channels gathered from the high-res x at the chunk's parity
   //   subpix 4 (data grad): M = 4*creal parity-major rows on the low-res dy, pixel-shuffled into dx
   int subpix, creal, cpb;
+  int xcd_remap;
 };
 
 __device__ __forceinline__ int src_index3(int mode, int oy0, int ox0, int r, int c, int Hin, int Win) {
@@ -97,9 +98,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  // XCD-aware block -> work map.  Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD
+  // b % 8), each with its own L2.  The ncob blocks that share one halo tile are therefore given
+  // CONSECUTIVE slots of ONE XCD (tile t lives on XCD t % 8), so the tile is fetched into one L2 once
+  // instead of into ncob of them.  Needs the tile count to be a multiple of 8 (any batch of 8k images).
   int b = blockIdx.x;
-  const int cob = b % a.ncob;
-  b /= a.ncob;
+  int cob;
+  if (a.xcd_remap) {
+    const int xcd = b & 7, q = b >> 3;
+    cob = q % a.ncob;
+    b = (q / a.ncob) * 8 + xcd;
+  } else {
+    cob = b % a.ncob;
+    b /= a.ncob;
+  }
   const int tx = b % a.tiles_x;
   b /= a.tiles_x;
   const int ty = b % a.tiles_y;
@@ -986,6 +998,11 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
 #ifndef EOVAE_CONV_NW4
 #define EOVAE_CONV_NW4 0
 #endif
+#ifndef EOVAE_XCD_REMAP
+#define EOVAE_XCD_REMAP 1
+#endif
+  a.xcd_remap = 0;
+  auto xcd_ok = [&](long long tiles) { return (EOVAE_XCD_REMAP && a.ncob > 1 && tiles % 8 == 0) ? 1 : 0; };
   // 16-row tiles when that still fills the chip (>= 2 blocks per CU), else 8-row tiles
   const long long blocks16 = (long long)N * cdiv(Hout, 16) * a.tiles_x * a.ncob;
   if (EOVAE_CONV_NW4) {  // two independent 4-wave blocks of 8 x 32 pixels per CU
@@ -995,11 +1012,13 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
     else hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 1, 4>), grid, dim3(256), 0, st, a);
   } else if (blocks16 >= 512) {
     a.tiles_y = cdiv(Hout, 16);
+    a.xcd_remap = xcd_ok(N * a.tiles_y * a.tiles_x);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
     if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 3, 8>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_bf16_kernel<16, 1, 8>), grid, dim3(512), 0, st, a);
   } else {
     a.tiles_y = cdiv(Hout, 8);
+    a.xcd_remap = xcd_ok(N * a.tiles_y * a.tiles_x);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob));
     if (precision == 3) hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 3, 8>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_bf16_kernel<8, 1, 8>), grid, dim3(512), 0, st, a);
