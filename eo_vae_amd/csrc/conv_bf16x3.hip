@@ -337,51 +337,73 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvBArgs a) {
     if (!(EOVAE_ABL & 4)) LDS_BARRIER();
   }
 
-  if (mshuffle) {  // pixel-shuffle store: parity (py,px) block -> y[n][co][2*oy+py][2*ox+px]
-    const int py = par1 >> 1, px = par1 & 1;
-    const size_t out_plane = (size_t)a.Hout * a.Wout * 4;
-    const int ox = ox0 + r;
+  // Epilogue.  Bias and residual are fetched by UNCONDITIONAL loads (clamped index) in batches of
+  // 4 channels x NI rows, then the batch is stored under its bounds mask.  Written the obvious way
+  // (`bias ? bias[co] : 0`, `if (res) v += res[o]` per element) every one of the 128 stores of a lane
+  // was preceded by s_waitcnt vmcnt(0) -- the previous store's acknowledgement and the residual's
+  // full latency, 128 times per block.
+  const int ox = ox0 + r;
+  const bool okx = ox < a.Wout;
+  const int chans = mshuffle ? a.creal : a.Cout;                    // channels of the stored tensor
+  const int co_blk = (mshuffle ? (cob - par1 * a.cpb) : cob) * BM;
+  const int co_base = co_blk + wco + 4 * h;
+  const int py = par1 >> 1, px = par1 & 1;
+  const size_t out_plane = mshuffle ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
+  float* yn = a.y + (size_t)n * chans * out_plane;
+  const float* rn = a.res ? a.res + (size_t)n * chans * out_plane : nullptr;
+  unsigned rowoff[NI];   // element offset of (row j, this lane's column) inside a channel plane
+  bool rowok[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int oy = oy0 + wrow + j;
+    rowok[j] = okx && oy < a.Hout;
+    const int oyc = oy < a.Hout ? oy : a.Hout - 1, oxc = okx ? ox : a.Wout - 1;
+    rowoff[j] = mshuffle ? (unsigned)((2 * oyc + py) * (2 * a.Wout) + 2 * oxc + px)
+                         : (unsigned)(oyc * a.Wout + oxc);
+  }
+  // FULL = the whole 128 co x TH x 32 tile lies inside the tensor (every layer of the model): plain
+  // stores, nothing predicated, so no wait is needed between them
+  auto epilogue = [&](auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int co = (cob - par1 * a.cpb) * BM + wco + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (co >= a.creal) continue;
-        const float bias = a.bias ? a.bias[co] : 0.f;
+      for (int qq = 0; qq < 4; ++qq) {
+        float bias4[4], rv[4][NI];
+        int coc[4];
+        bool cok[4];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int oy = oy0 + wrow + j;
-          if (oy < a.Hout && ox < a.Wout) {
-            const size_t o = ((size_t)n * a.creal + co) * out_plane +
-                             (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px;
-            a.y[o] = acc[i][j][q] + bias;
+        for (int k = 0; k < 4; ++k) {
+          const int co = co_base + i * 32 + k + 8 * qq;
+          cok[k] = FULL || co < chans;
+          coc[k] = cok[k] ? co : chans - 1;
+          bias4[k] = a.bias ? a.bias[coc[k]] : 0.f;       // uniform branch, unconditional load
+        }
+        if (rn) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) rv[k][j] = rn[(size_t)coc[k] * out_plane + rowoff[j]];
+        }
+        float v[4][NI];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            v[k][j] = acc[i][j][4 * qq + k] + bias4[k];
+            if (rn) v[k][j] += rv[k][j];
+            if (!FULL) asm volatile("" : "+v"(v[k][j]));  // finish the batch's arithmetic before its masked stores
           }
-        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            if (FULL || (cok[k] && rowok[j])) yn[(size_t)coc[k] * out_plane + rowoff[j]] = v[k][j];
       }
     }
-    return;
-  }
-  const size_t out_plane = (size_t)a.Hout * a.Wout;
-  const int ox = ox0 + r;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int co = cob * BM + wco + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (co >= a.Cout) continue;
-      const float bias = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int oy = oy0 + wrow + j;
-        if (oy < a.Hout && ox < a.Wout) {
-          const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wout + ox;
-          float v = acc[i][j][q] + bias;
-          if (a.res) v += a.res[o];
-          a.y[o] = v;
-        }
-      }
-    }
-  }
+  };
+  const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && co_blk + BM <= chans;
+  if (full_tile) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------
