@@ -226,24 +226,67 @@ __global__ __launch_bounds__(512, EOVAE_GEMM_MINB) void gemm_bf16_kernel(GemmBAr
   else if ((A_KC || B_KC) && g.vec) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, 1>{});
 
+  // Epilogue in batches of 4 rows x 2 column tiles: bias / residual by unconditional loads from clamped
+  // indices, then the batch is stored (plain, atomic, or masked at the tensor edge).  The per-element
+  // form (`bias ? bias[m] : 0`, `if (res) v += res[o]`) put an s_waitcnt vmcnt(0) in front of every store.
+  const bool lead = ks_id == 0;
+  const float* biasp = lead ? g.bias : nullptr;
+  const float* resp = (lead && g.res) ? g.res + bat * g.batC : nullptr;
+  auto epilogue = [&](auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_t)::value;
+    long long ncol[2];
+    bool nok[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + wm + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (m >= g.M) continue;
-      const float bias = (g.bias && ks_id == 0) ? g.bias[m] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn + j * 32 + r;
-        if (n >= g.N) continue;
-        const long long o = (long long)m * g.scm + (long long)n * g.scn;
-        float v = acc[i][j][q] * g.alpha + bias;
-        if (g.res && ks_id == 0) v += g.res[bat * g.batC + o];
-        if (g.atomic) atomicAdd(&C[o], v);
-        else C[o] = v;
-      }
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + j * 32 + r;
+      nok[j] = FULL || n < g.N;
+      ncol[j] = (long long)(nok[j] ? n : g.N - 1) * g.scn;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float bias4[4], rv[4][2], v[4][2];
+        long long mrow[4];
+        bool mok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m = m0 + wm + i * 32 + k + 8 * qq + 4 * h;
+          mok[k] = FULL || m < g.M;
+          const int mc = mok[k] ? m : g.M - 1;
+          mrow[k] = (long long)mc * g.scm;
+          bias4[k] = biasp ? biasp[mc] : 0.f;
+        }
+        if (resp) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rv[k][j] = resp[mrow[k] + ncol[j]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            v[k][j] = acc[i][j][4 * qq + k] * g.alpha + bias4[k];
+            if (resp) v[k][j] += rv[k][j];
+            if (!FULL) asm volatile("" : "+v"(v[k][j]));
+          }
+        if (g.atomic) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (FULL || (mok[k] && nok[j])) atomicAdd(&C[mrow[k] + ncol[j]], v[k][j]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (FULL || (mok[k] && nok[j])) C[mrow[k] + ncol[j]] = v[k][j];
+        }
+      }
+  };
+  if (m0 + BM <= g.M && n0 + BN <= g.N) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 template <int NT>
