@@ -6,6 +6,8 @@ SURVEY.md 2b K14); the convolution with the generated kernel and its three gradi
 the HIP implicit-GEMM kernels."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -135,8 +137,37 @@ class DynamicConv_decoder(_DynamicBase):
         w = weight.view(wvs_microns.size(0), k, k, self.embed_dim).permute(0, 3, 1, 2)
         return w * self.scaler, bias.squeeze() * self.scaler
 
+    # The generator is ~50 tiny library GEMMs that leave most of the chip idle and whose result is needed
+    # only by the LAST op of the decoder: Decoder.forward starts it on a side HIP stream before the body
+    # (prefetch), and forward() joins the stream here.  Autograd replays each op's backward on the stream
+    # of its forward, so the generator's backward overlaps the decoder body's backward the same way.
+    _side_stream = None
+    _pending = None
+
+    def prefetch(self, waves):
+        if not waves.is_cuda or os.environ.get('EOVAE_HYPERNET_STREAM', '1') == '0':
+            return
+        cls = DynamicConv_decoder
+        if cls._side_stream is None:
+            cls._side_stream = torch.cuda.Stream()
+            from .parallel import SIDE_STREAMS
+            SIDE_STREAMS.append(cls._side_stream)
+        side, main = cls._side_stream, torch.cuda.current_stream()
+        side.wait_stream(main)          # parameters / wavelengths written on the main stream
+        with torch.cuda.stream(side):
+            w, b = self.get_distillation_weight(waves)
+            b = (b * self.scaler).reshape(-1)
+        self._pending = (w, b)
+
     def forward(self, img_feat, waves):
-        w, b = self.get_distillation_weight(waves)
-        b = (b * self.scaler).reshape(-1)
+        if self._pending is not None:
+            w, b = self._pending
+            self._pending = None
+            main = torch.cuda.current_stream()
+            main.wait_stream(DynamicConv_decoder._side_stream)
+            w.record_stream(main), b.record_stream(main)
+        else:
+            w, b = self.get_distillation_weight(waves)
+            b = (b * self.scaler).reshape(-1)
         self.weight = w  # read by EOFluxVAE.get_last_layer (:708)
         return ops.conv2d(img_feat, w, b, None, 'normal')

@@ -107,6 +107,8 @@ class Decoder(nn.Module):
             self.conv_out = Conv2d(block_in, out_ch, 3)
 
     def forward(self, z, wvs=None):
+        if self.use_dynamic_ops and wvs is not None:
+            self.conv_out.prefetch(wvs)   # output-kernel generator on a side stream, joined at conv_out
         h = self.conv_in(self.post_quant_conv(z))
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for level in reversed(range(self.num_resolutions)):

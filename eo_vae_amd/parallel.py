@@ -39,6 +39,13 @@ def init_distributed(backend: str | None = None, force: bool = False):
     return rank, world, local
 
 
+# HIP streams other than the main one on which parts of the backward pass run (e.g. the decoder's
+# kernel generator, dynamic_conv.DynamicConv_decoder.prefetch).  A bucket may hold gradients produced on
+# several of them, so its all-reduce is ordered after all of them, not only after the stream whose hook
+# happened to complete the bucket.
+SIDE_STREAMS: list = []
+
+
 class BucketedGradReducer:
     def __init__(self, flat, group=None, bucket_mb: float = 48.0, force: bool = False):
         """`force` keeps the hooks and collectives even in a world of 1 (RCCL rehearsal on one GPU)."""
@@ -63,6 +70,7 @@ class BucketedGradReducer:
         self.launched = [False] * len(self.buckets)
         self.works = []
         self.handles = []
+        self.main_stream = torch.cuda.current_stream() if flat.grad.is_cuda else None
         if self.active:
             for p in flat.params:
                 if p.requires_grad:
@@ -84,6 +92,11 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         start, end, _ = self.buckets[b]
+        if self.flat.grad.is_cuda:
+            cur = torch.cuda.current_stream()
+            for st in [self.main_stream] + SIDE_STREAMS:
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         self.works.append(dist.all_reduce(self.flat.grad[start:end], op=op, group=self.group,
                                           async_op=True))
