@@ -62,6 +62,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Gather of per-parameter gradient tensors into the flat gradient buffer: one block per table row
+// (src pointer as integer or 0 for "no gradient" => zeros, destination element offset, element count
+// <= 16384).  Replaces one autograd accumulate-add launch per parameter (363 per step) plus the zero fill.
+__global__ __launch_bounds__(256) void multi_gather_kernel(const long long* __restrict__ table,
+                                                           float* __restrict__ flat) {
+  const long long* row = table + (size_t)blockIdx.x * 3;
+  const float* src = reinterpret_cast<const float*>(row[0]);
+  float* dst = flat + row[1];
+  const int n = (int)row[2];
+  const bool vec = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  if (vec) {
+    const int n4 = n >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      float4 v = src ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(dst)[i] = v;
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) dst[i] = src ? src[i] : 0.f;
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src ? src[i] : 0.f;
+  }
+}
+
 __global__ void scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ coef,
                              float s) {
   const float cs = (coef ? coef[1] : 1.f) * s;
@@ -101,6 +123,14 @@ int eovae_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                      beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), clip, grad_scale, weight_decay);
   EOVAE_CHECK_LAUNCH("eovae_adam_step");
+  return EOVAE_OK;
+}
+
+// table: nrows x {src address (0 = zeros), destination element offset in flat, element count} (device, int64)
+int eovae_multi_gather(const long long* table, int nrows, float* flat, void* stream) {
+  EOVAE_CHECK_ARG(table && flat && nrows > 0, "multi_gather: bad argument");
+  hipLaunchKernelGGL(multi_gather_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, table, flat);
+  EOVAE_CHECK_LAUNCH("eovae_multi_gather");
   return EOVAE_OK;
 }
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     'eovae_grad_norm': (_i, [_p, _sz, _f, _p, _p, _p]),
     'eovae_adam_step': (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _p, _f, _f, _p]),
     'eovae_scale_inplace': (_i, [_p, _sz, _p, _f, _p]),
+    'eovae_multi_gather': (_i, [_p, _i, _p, _p]),
 }
 
 _lib = None

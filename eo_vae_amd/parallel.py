@@ -97,6 +97,9 @@ class BucketedGradReducer:
             for st in [self.main_stream] + SIDE_STREAMS:
                 if st is not None and st != cur:
                     cur.wait_stream(st)
+        if getattr(self.flat, 'detached', False):   # this bucket's gradients -> flat buffer, one launch
+            idxs = self.buckets[b][2]
+            self.flat.gather(min(idxs), max(idxs) + 1)
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         self.works.append(dist.all_reduce(self.flat.grad[start:end], op=op, group=self.group,
                                           async_op=True))
@@ -114,6 +117,8 @@ class BucketedGradReducer:
             w.wait()
         if not self.use_avg:
             self.flat.grad.mul_(1.0 / self.world)
+        if getattr(self.flat, 'detached', False):
+            self.flat.gathered = True       # every bucket was gathered on its way to the all-reduce
         self.works = []
         self.pending = [len(m) for _, _, m in self.buckets]
         self.launched = [False] * len(self.buckets)

@@ -214,6 +214,10 @@ int eovae_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
                     float beta2, float eps, int step, const float* clip, float grad_scale,
                     float weight_decay, void* stream);
 int eovae_scale_inplace(float* g, size_t n, const float* clip, float s, void* stream);
+/* per-parameter gradient tensors -> flat gradient buffer in ONE launch (instead of one autograd
+ * accumulate-add per parameter): table = nrows x {source address or 0 (zeros), destination element offset,
+ * element count <= 16384}, int64, device memory */
+int eovae_multi_gather(const long long* table, int nrows, float* flat, void* stream);
 
 /* ----------------------------------------------------------------------------------------
  * encode_latents.py running statistics (csrc/stats.hip): RunningStatsButFast.update

@@ -98,6 +98,7 @@ def test_two_rank_train_step_on_one_gpu():
         opt.zero_grad()
         loss, _ = m.loss_fn(inputs=batch['image'], wvs=batch['wvs'], reconstructions=recon)
         loss.backward()
+        opt.flat.gather()           # single-process path: parameter gradients -> flat buffer
         grads.append(opt.flat.grad.detach().cpu().clone())
     avg = (grads[0] + grads[1]) / 2
     # averaged gradient (atomics in wgrad make the last bits run-dependent)

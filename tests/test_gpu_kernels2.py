@@ -350,3 +350,33 @@ def test_encode_pairs_npz_contract(tmp_path, prec):
     assert set(js) == {'lr_latent', 'hr_latent'} and set(js['lr_latent']) == {'mean', 'std', 'var', 'min', 'max', 'count'}
     assert js['lr_latent']['count'] == [4 * 8 * 8]
     assert len(os.listdir(tmp_path)) == 5
+
+
+def test_flat_gradient_gather_matches_views():
+    """FlatParams(detached_grads=True).gather(): autograd's per-parameter gradient tensors land in the
+    flat buffer exactly as the in-place view accumulation would have put them (incl. a parameter without
+    gradient -> zeros, sub-range gathers, and a tensor larger than one table row)."""
+    from eo_vae_amd.optim import FlatParams
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Linear(300, 70), torch.nn.Linear(70, 5), torch.nn.Linear(5, 3)).cuda()
+    x = torch.randn(4, 300, device='cuda')
+    m_v, m_d = make(), make()
+    f_v, f_d = FlatParams(list(m_v.parameters())), FlatParams(list(m_d.parameters()), detached_grads=True)
+    assert f_d.row_span[0][1] - f_d.row_span[0][0] == 2      # 21000 elements -> two rows
+    for m, f in ((m_v, f_v), (m_d, f_d)):
+        f.zero_grad()
+        m[1](m[0](x)).square().sum().backward()               # last layer gets no gradient
+    assert all(p.grad is None for p in m_d[2].parameters())
+    f_d.grad.fill_(7.0)
+    f_d.gather()
+    torch.cuda.synchronize()
+    for i in range(len(f_v.params)):
+        a, b = f_v.span(i)
+        assert torch.equal(f_d.grad[a:b], f_v.grad[a:b]), i
+    f_d.grad.fill_(7.0)
+    f_d.gather(2, 4)                                           # one "bucket": parameters 2 and 3 only
+    torch.cuda.synchronize()
+    a, b = f_v.span(2)
+    assert torch.equal(f_d.grad[a:b], f_v.grad[a:b]) and float(f_d.grad[0]) == 7.0
