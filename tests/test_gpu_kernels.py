@@ -121,7 +121,8 @@ def test_conv3x3_split_bf16(n, cin, cout, h, w, mode, precision, tol):
 
 @pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 192, 16, 16), (4, 512, 512, 32, 32), (2, 32, 32, 8, 8),
-                                            (1, 256, 128, 40, 24), (3, 64, 64, 9, 7)])
+                                            (1, 256, 128, 40, 24), (3, 64, 64, 9, 7),
+                                            (1, 48, 40, 10, 6)])     # K % 32 != 0: predicated stage loads
 def test_conv1x1_split_bf16(n, cin, cout, h, w, precision, tol):
     _lowp_case(n, cin, cout, h, w, 1, 'normal', precision, tol)
 

@@ -380,3 +380,24 @@ def test_flat_gradient_gather_matches_views():
     torch.cuda.synchronize()
     a, b = f_v.span(2)
     assert torch.equal(f_d.grad[a:b], f_v.grad[a:b]) and float(f_d.grad[0]) == 7.0
+
+
+@pytest.mark.parametrize('m,n,k,off', [(128, 256, 64, 0), (130, 250, 96, 0), (64, 96, 32, 1), (200, 70, 40, 3)])
+def test_gemm_bf16x3_load_paths(m, n, k, off):
+    """The three operand-load paths of the split-bf16 GEMM (dwordx4 pairs for aligned k-contiguous
+    operands, scalar unconditional loads, predicated loads for K % 32 != 0) and the masked epilogue,
+    C-ABI called directly: A [m][k] and B^T [n][k] both k-contiguous, optionally misaligned by `off` floats."""
+    from eo_vae_amd import lib as L
+    gen = torch.Generator().manual_seed(m + n + k)
+    a_buf = torch.randn(m * k + 8, generator=gen).cuda()
+    b_buf = torch.randn(n * k + 8, generator=gen).cuda()
+    A, Bt = a_buf[off:off + m * k].view(m, k), b_buf[off:off + n * k].view(n, k)
+    C = torch.empty(m, n, device='cuda')
+    bias = torch.randn(m, generator=gen).cuda()
+    res = torch.randn(m, n, generator=gen).cuda()
+    ptr = lambda t: t.data_ptr()
+    L.check(L.load().eovae_gemm_bf16x3(ptr(A), ptr(Bt), ptr(C), ptr(bias), ptr(res), 1, m, n, k,
+                                       k, 1, 1, k, n, 1, 0, 0, 0, 0.5, 1, 0, 3, 1, 0, 0, L.stream()), 'gemm')
+    torch.cuda.synchronize()
+    ref = 0.5 * (A.double() @ Bt.double().T) + bias.double()[:, None] + res.double()
+    assert rel(C, ref) < 2e-5
