@@ -103,3 +103,45 @@ def test_full_size_cfg1_reconstruct(golden):
     torch.cuda.synchronize()
     assert rel(rec[:, :, ::8, ::8], g['recon_sub']) < REL_OUT
     assert rel(spat[:, :, ::2, ::2], g['spatial_sub']) < REL_OUT
+
+
+def test_full_size_kernel_properties():
+    """BASELINE cfg2 sizes (B=16, 128 ch, 256x256 -- far beyond what the CPU oracle finishes in seconds):
+    size-independent properties of the dominant kernels instead of an element-wise oracle.
+      * convolution (fwd, data-grad, weight-grad) is linear in each argument;
+      * the 3x3 kernel with a one-hot centre tap is the identity channel map;
+      * GroupNorm+SiLU output is invariant to a per-group affine change of its input;
+      * bias gradient = plain sum of dy."""
+    from eo_vae_amd import ops
+    torch.manual_seed(0)
+    B, C, H = 16, 128, 256
+    x1 = torch.randn(B, C, H, H, device='cuda')
+    x2 = torch.randn(B, C, H, H, device='cuda')
+    w = (torch.randn(C, C, 3, 3, device='cuda') / (C * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(C, device='cuda').requires_grad_(True)
+    with torch.no_grad():
+        y1, y2 = ops.conv2d(x1, w, None, None, 'normal'), ops.conv2d(x2, w, None, None, 'normal')
+        y12 = ops.conv2d(0.5 * x1 - 2.0 * x2, w, None, None, 'normal')
+        assert rel(y12, 0.5 * y1 - 2.0 * y2) < 5e-5                       # linear in x
+        eye = torch.zeros(C, C, 3, 3, device='cuda')
+        eye[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+        assert rel(ops.conv2d(x1, eye, None, None, 'normal'), x1) < 1e-5    # split-bf16 reproduces fp32 data
+    xa = x1.clone().requires_grad_(True)
+    ya = ops.conv2d(xa, w, b, None, 'normal')
+    gy = torch.randn_like(ya)
+    ya.backward(gy)
+    gx_a, gw_a, gb_a = xa.grad.clone(), w.grad.clone(), b.grad.clone()
+    w.grad = None; b.grad = None
+    xb = x1.clone().requires_grad_(True)
+    ops.conv2d(xb, w, b, None, 'normal').backward(-3.0 * gy)
+    assert rel(xb.grad, -3.0 * gx_a) < 5e-5 and rel(w.grad, -3.0 * gw_a) < 1e-4    # linear in dy (atomics reorder)
+    assert rel(gb_a, gy.sum((0, 2, 3))) < 2e-5
+    del xa, xb, ya, y1, y2, y12
+    gamma = torch.randn(C, device='cuda'); beta = torch.randn(C, device='cuda')
+    with torch.no_grad():
+        z1 = ops.group_norm_silu(x1, gamma, beta)
+        scale = torch.rand(B, 32, 1, 1, 1, device='cuda') + 0.5          # per (image, group) affine change
+        shift = torch.randn(B, 32, 1, 1, 1, device='cuda')
+        x3 = (x1.view(B, 32, C // 32, H, H) * scale + shift).view(B, C, H, H)
+        assert rel(ops.group_norm_silu(x3, gamma, beta), z1) < 2e-4      # eps 1e-6 and fp32 statistics
+    torch.cuda.synchronize()
