@@ -101,10 +101,36 @@ class _DynamicBase(nn.Module):
         self.fclayer = FCResLayer(wv_planes)
         self.weight_generator.apply(_xavier_linear)
         self.fclayer.apply(_xavier_linear)
+        self._gen_cache = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._gen_cache.clear())
 
     def _raw(self, wvs):
+        """Generator output for `wvs`.  In inference (eval mode, no grad) the result only depends on the
+        wavelengths and the parameters, so it is cached per wavelength tensor ('cacheable per
+        wvs in eval'); train(), load_state_dict() and .to() drop the cache."""
+        cacheable = not self.training and not torch.is_grad_enabled()
+        if cacheable:
+            # keyed on the tensor's identity and version, not its values: reading values back from the
+            # GPU would synchronise the host with the stream on every batch
+            key = (wvs.data_ptr(), wvs._version, tuple(wvs.shape), wvs.device, wvs.dtype)
+            hit = self._gen_cache.get(key)
+            if hit is not None:
+                return hit
         waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
-        return self.weight_generator(self.fclayer(waves))
+        out = self.weight_generator(self.fclayer(waves))
+        if cacheable:
+            if len(self._gen_cache) >= 16:
+                self._gen_cache.clear()
+            self._gen_cache[key] = out
+        return out
+
+    def train(self, mode: bool = True):
+        self._gen_cache.clear()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._gen_cache.clear()
+        return super()._apply(fn, *args, **kwargs)
 
 
 class DynamicConv(_DynamicBase):
