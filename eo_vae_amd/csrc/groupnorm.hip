@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   const float g = gamma[c], b = beta[c];
   const size_t base = (size_t)plane * HW;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    float xh = (x[base + i] - mean) * rstd;
-    float dz = dy[base + i];
+  auto term = [&](float xv, float dyv) {
+    float xh = (xv - mean) * rstd;
+    float dz = dyv;
     if (SILU) {
       float z = xh * g + b;
       float sg = 1.f / (1.f + __expf(-z));
@@ -125,6 +125,15 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     }
     s1 += dz;
     s2 += dz * xh;
+  };
+  if ((HW & 3) == 0) {   // 16-byte loads: 4x fewer memory instructions for the same bytes in flight
+    for (int i = 4 * threadIdx.x; i < HW; i += 1024) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + base + i);
+      term(xv.x, dv.x); term(xv.y, dv.y); term(xv.z, dv.z); term(xv.w, dv.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) term(x[base + i], dy[base + i]);
   }
   __shared__ double red[8];
   double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
@@ -183,17 +192,40 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   const int beg = chunk * per;
   int end = beg + per;
   if (end > HW) end = HW;
-  for (int i = beg + threadIdx.x; i < end; i += 256) {
-    float xh = (x[base + i] - mean) * rstd;
-    float dz = dy[base + i];
+  auto elem = [&](float xv, float dyv, float addv) {
+    float xh = (xv - mean) * rstd;
+    float dz = dyv;
     if (SILU) {
       float z = xh * g + b;
       float sg = 1.f / (1.f + __expf(-z));
       dz *= sg * (1.f + z * (1.f - sg));
     }
-    float v = rstd * (dz * g - m1 - xh * m2);
-    if (dx_add) v += dx_add[base + i];
-    dx[base + i] = v;
+    return rstd * (dz * g - m1 - xh * m2) + addv;
+  };
+  if ((HW & 3) == 0 && (per & 3) == 0) {
+    if (dx_add) {   // uniform: two straight-line loops, no load under a per-element condition
+      for (int i = beg + 4 * threadIdx.x; i < end; i += 1024) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + base + i);
+        const float4 av = *reinterpret_cast<const float4*>(dx_add + base + i);
+        float4 o;
+        o.x = elem(xv.x, dv.x, av.x); o.y = elem(xv.y, dv.y, av.y);
+        o.z = elem(xv.z, dv.z, av.z); o.w = elem(xv.w, dv.w, av.w);
+        *reinterpret_cast<float4*>(dx + base + i) = o;
+      }
+    } else {
+      for (int i = beg + 4 * threadIdx.x; i < end; i += 1024) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + base + i);
+        float4 o;
+        o.x = elem(xv.x, dv.x, 0.f); o.y = elem(xv.y, dv.y, 0.f);
+        o.z = elem(xv.z, dv.z, 0.f); o.w = elem(xv.w, dv.w, 0.f);
+        *reinterpret_cast<float4*>(dx + base + i) = o;
+      }
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += 256)
+      dx[base + i] = elem(x[base + i], dy[base + i], dx_add ? dx_add[base + i] : 0.f);
   }
 }
 
