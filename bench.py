@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -98,6 +99,34 @@ def cpu_baseline(channels, wvs_list, micro_batch=2, threads=None):
     return {'value': micro_batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': f'1 full train step (fwd+L1+KL+bwd+clip+Adam) at micro-batch {micro_batch}, '
                       f'{channels}x256x256, fp32, torch CPU {threads} threads, {dt:.1f} s'}
+
+
+def parity_vs_reference():
+    """BASELINE.json's second half of the metric: error of the GPU path against the REFERENCE's CPU output
+    on config 1 (full-size model, S2RGB 3x256x256, batch 2, reconstruct()), from the committed fixture
+    tests/golden/full_cfg1.npz that tests/golden/gen_golden.py produced by running the reference itself.
+    Part of the checker leg (imports oracle/ for the closed-form parameter fill and the seeded input)."""
+    import numpy as np
+    from oracle import eo_vae_cpu as O
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'full_cfg1.npz'))
+    model = build_model(3)
+    O.det_fill(model, seed=31)          # the rule the fixture's reference model was filled with
+    model = model.cuda().eval()
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB']).cuda()
+    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    assert abs(float(x.double().sum()) - float(g['x_checksum'])) < 1e-6 * abs(float(g['x_checksum'])) + 1e-6
+    with torch.no_grad():
+        rec = model.reconstruct(x.cuda(), wvs)[:, :, ::8, ::8].double().cpu()
+        lat = model.encode_spatial_normalized(x.cuda(), wvs)[:, :, ::2, ::2].double().cpu()
+    ref_r, ref_l = torch.from_numpy(g['recon_sub']).double(), torch.from_numpy(g['spatial_sub']).double()
+    mse = float(((rec - ref_r) ** 2).mean())
+    rng = float(ref_r.max() - ref_r.min())
+    return {'workload': 'cfg1: reconstruct(), S2RGB 3x256x256, batch 2, full-size model, deterministic fill',
+            'reference': 'reference CPU fp32 output (tests/golden/full_cfg1.npz, every 8th pixel / 2nd latent)',
+            'recon_max_rel_err': float((rec - ref_r).abs().max() / ref_r.abs().max()),
+            'latent_max_rel_err': float((lat - ref_l).abs().max() / ref_l.abs().max()),
+            'recon_psnr_db': float(10.0 * math.log10(rng * rng / mse)) if mse > 0 else float('inf'),
+            'tolerance': 1e-3}
 
 
 def main():
@@ -232,6 +261,9 @@ def main():
             out.pop('hbm_roofline_frac', None)
             out['step_flops_tflops'] = round(274.6e9 * ips / world / 1e12, 2)
         if not args.no_cpu_baseline and world == 1 and args.workload == 'cfg2':
+            del driver, model
+            torch.cuda.empty_cache()
+            out['parity'] = parity_vs_reference()
             out['cpu_baseline'] = cpu_baseline(C, wl)
         print(json.dumps(out), flush=True)
     if world > 1:
