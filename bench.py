@@ -212,7 +212,7 @@ def main():
         k_ms, k_flops, k_n = timer.totals()
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
-            with open(os.path.join(ROOT, 'profiles', 'r01h_pmc_hbm_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01i_pmc_hbm_traffic.json')) as f:
                 traffic = json.load(f)['kernels']['conv3x3_bf16_kernel']['traffic_bytes_per_launch_corrected']
         except Exception:
             pass
