@@ -22,6 +22,7 @@ class FlatParams:
         all of them -- or one bucket's worth -- into the flat buffer with ONE HIP launch."""
 
     CHUNK = 16384  # elements per gather-table row
+    NBUF = 4       # pointer-table slots (>= buckets in flight + 1)
 
     def __init__(self, params, detached_grads: bool = False):
         self.params = [p for p in params]
@@ -64,13 +65,14 @@ class FlatParams:
         self._row_param = np.asarray(rows_param, dtype=np.int64)
         self._row_src = np.asarray(rows_src, dtype=np.int64)
         nrows = len(rows_param)
-        # two pinned staging tables (a step may be built while the previous upload is still in flight)
-        self._host = [torch.empty((nrows, 3), dtype=torch.int64).pin_memory() for _ in range(2)]
+        # a small ring of pinned staging tables: a gather may be built while earlier uploads are still in
+        # flight, and re-using a slot only waits for the gather issued NBUF calls ago
+        self._host = [torch.empty((nrows, 3), dtype=torch.int64).pin_memory() for _ in range(self.NBUF)]
         for h in self._host:
             h[:, 1] = torch.from_numpy(np.asarray(rows_dst, dtype=np.int64))
             h[:, 2] = torch.from_numpy(np.asarray(rows_cnt, dtype=np.int64))
-        self._dev = [torch.empty((nrows, 3), dtype=torch.int64, device=dev) for _ in range(2)]
-        self._events = [None, None]
+        self._dev = [torch.empty((nrows, 3), dtype=torch.int64, device=dev) for _ in range(self.NBUF)]
+        self._events = [None] * self.NBUF
         self._flip = 0
         self._keep = []          # contiguous copies that must outlive the gather launch
         self.gathered = False
@@ -84,7 +86,7 @@ class FlatParams:
         last = len(self.params) if last is None else last
         r0, r1 = self.row_span[first][0], self.row_span[last - 1][1]
         k = self._flip
-        self._flip ^= 1
+        self._flip = (k + 1) % self.NBUF
         if self._events[k] is not None:
             self._events[k].synchronize()
         base = np.zeros(len(self.params), dtype=np.int64)
