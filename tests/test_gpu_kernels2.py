@@ -401,3 +401,25 @@ def test_gemm_bf16x3_load_paths(m, n, k, off):
     torch.cuda.synchronize()
     ref = 0.5 * (A.double() @ Bt.double().T) + bias.double()[:, None] + res.double()
     assert rel(C, ref) < 2e-5
+
+
+def test_fused_adam_views_and_detached_modes_agree(monkeypatch):
+    """EOVAE_DETACHED_GRADS=0 (p.grad = views of the flat buffer, autograd accumulates in place) and the
+    default (gradients gathered by one launch) must give the same flat gradient, norm and update."""
+    from eo_vae_amd.optim import FusedAdam
+    x = torch.randn(8, 40, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    outs = []
+    for mode in ('0', '1'):
+        monkeypatch.setenv('EOVAE_DETACHED_GRADS', mode)
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Tanh(), torch.nn.Linear(300, 7)).cuda()
+        opt = FusedAdam(list(m.parameters()), lr=1e-2)
+        assert opt.flat.detached == (mode == '1')
+        for _ in range(3):
+            opt.zero_grad()
+            m(x).square().mean().backward()
+            norm = opt.clip_grad_norm(0.5)
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append((opt.flat.grad.clone(), float(norm), opt.flat.data.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
