@@ -105,24 +105,38 @@ class _DynamicBase(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._gen_cache.clear())
 
     def _raw(self, wvs):
-        """Generator output for `wvs`.  In inference (eval mode, no grad) the result only depends on the
-        wavelengths and the parameters, so it is cached per wavelength tensor ('cacheable per
-        wvs in eval'); train(), load_state_dict() and .to() drop the cache."""
+        """Generator output for `wvs`.  In inference (eval mode, no grad) the result depends only on the
+        wavelength VALUES and the parameters, so it is cached (SURVEY K14: 'cacheable per wvs in eval');
+        train(), load_state_dict() and .to() drop the cache.
+
+        Two levels.  (1) identity: the cache keeps a strong reference to every tensor object it has
+        seen, so `id(wvs)` cannot be recycled while the entry lives, and `_version` catches in-place
+        edits -- the same tensor passed again costs no host read.  (2) values: a tensor object not seen
+        before is read back once (a [C]-element copy; the only stream synchronisation) and looked up by
+        its values, then registered under (1).  A key made of data_ptr/_version alone (round 1) handed
+        a recycled address the previous wavelengths' kernels."""
         cacheable = not self.training and not torch.is_grad_enabled()
         if cacheable:
-            # keyed on the tensor's identity and version, not its values: reading values back from the
-            # GPU would synchronise the host with the stream on every batch
-            key = (wvs.data_ptr(), wvs._version, tuple(wvs.shape), wvs.device, wvs.dtype)
-            hit = self._gen_cache.get(key)
-            if hit is not None:
-                return hit
+            hit = self._gen_cache.get(('id', id(wvs)))
+            if hit is not None and hit[0] is wvs and hit[1] == wvs._version:
+                return hit[2]
+            vkey = ('val', str(wvs.device), wvs.dtype, tuple(wvs.shape),
+                    tuple(wvs.detach().reshape(-1).tolist()))
+            out = self._gen_cache.get(vkey)
+            if out is not None:
+                self._remember(('id', id(wvs)), (wvs, wvs._version, out))
+                return out
         waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
         out = self.weight_generator(self.fclayer(waves))
         if cacheable:
-            if len(self._gen_cache) >= 16:
-                self._gen_cache.clear()
-            self._gen_cache[key] = out
+            self._remember(vkey, out)
+            self._remember(('id', id(wvs)), (wvs, wvs._version, out))
         return out
+
+    def _remember(self, key, value, limit=32):
+        if len(self._gen_cache) >= limit:
+            self._gen_cache.clear()
+        self._gen_cache[key] = value
 
     def train(self, mode: bool = True):
         self._gen_cache.clear()

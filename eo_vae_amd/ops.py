@@ -108,8 +108,31 @@ def conv_raw(x, wp, kp, mp, bias, residual, cout, ks, mode, out_scale=1.0):
 #   'f32'    exact fp32 on v_mfma_f32_32x32x2_f32 (csrc/conv_f32.hip)
 #   'bf16x3' split-bf16, 3 bf16 MFMAs per step, fp32-grade (~2^-17)  (csrc/conv_bf16x3.hip)
 #   'bf16'   plain bf16 operands, fp32 accumulate (fast mode; does NOT meet the 1e-3 parity bar)
-CONV_PRECISION = os.environ.get('EOVAE_CONV_PRECISION', 'bf16x3')
+DEFAULT_PRECISION = os.environ.get('EOVAE_CONV_PRECISION', 'bf16x3')   # the parity path
+CONV_PRECISION = DEFAULT_PRECISION
 _PREC = {'bf16x3': 3, 'bf16': 1}
+
+
+class precision_scope:
+    """`with ops.precision_scope('bf16'):` -- arithmetic mode for the convolutions / GEMMs issued inside
+    the block; the previous mode comes back on exit (also on an exception).  Conv2dFn records the mode
+    of its forward and replays its backward in the same mode, so a scope that ends between forward
+    and backward cannot mix code paths."""
+
+    def __init__(self, mode):
+        if mode not in ('f32', 'bf16x3', 'bf16'):
+            raise ValueError(f'unknown conv precision {mode!r}')
+        self.mode = mode
+
+    def __enter__(self):
+        global CONV_PRECISION
+        self.prev, CONV_PRECISION = CONV_PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_PRECISION
+        CONV_PRECISION = self.prev
+        return False
 
 
 def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
@@ -329,10 +352,16 @@ class Conv2dFn(torch.autograd.Function):
             y = conv_raw(x, wp, kp, mp, bias_c, res, cout, ks, m)
         ctx.save_for_backward(x, weight)
         ctx.mode, ctx.has_bias, ctx.has_res = m, bias is not None, residual is not None
+        ctx.prec = CONV_PRECISION
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        with precision_scope(ctx.prec):   # same arithmetic as the forward, whatever the global says now
+            return Conv2dFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = _c(dy)
         m = ctx.mode

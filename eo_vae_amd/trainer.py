@@ -39,10 +39,15 @@ class Trainer:
         # '32-true' (default) = the parity path (split-bf16, fp32-grade); '16-mixed' / 'bf16-mixed' = the
         # matrix cores on plain bf16 operands with fp32 storage and accumulation -- this build's mixed
         # precision: ~1e-2 relative error, i.e. OUTSIDE the 1e-3 parity bar, opt-in only.
+        # The mode is a property of THIS trainer's fit() (ops.precision_scope around the loop), not a
+        # process-wide switch: a later 32-true Trainer, bench run or inference call is unaffected.
+        # Both '16-mixed' (fp16 autocast in the reference) and 'bf16-mixed' map to bf16 operands:
+        # gfx950 runs f16 and bf16 MFMAs at the same rate and bf16 needs no loss scaling.
         self.precision = str(precision)
+        from . import ops
+        self.conv_precision = ops.DEFAULT_PRECISION
         if self.precision in ('16-mixed', 'bf16-mixed', '16', 'bf16'):
-            from . import ops
-            ops.CONV_PRECISION = 'bf16'
+            self.conv_precision = 'bf16'
             print(f"precision={self.precision}: convolutions / GEMMs on plain bf16 MFMA operands "
                   '(fp32 accumulate); not within the 1e-3 parity bar', flush=True)
         elif self.precision not in ('32-true', '32', 'None'):
@@ -76,6 +81,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ fit
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
+        from . import ops
+        with ops.precision_scope(self.conv_precision):
+            return self._fit(model, datamodule, train_dataloaders, val_dataloaders)
+
+    def _fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
         self.rank, self.world, self.local_rank = init_distributed()
         if not torch.cuda.is_available():
             from .lib import EovaeError

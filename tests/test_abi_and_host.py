@@ -153,3 +153,36 @@ def test_pixel_shuffle_helpers_match_einops():
     assert torch.equal(_unpack2x2(p), z)
     z5 = torch.randn(3, 2, 5, 6, 8)
     assert torch.equal(_pack2x2(z5), rearrange(z5, '... c (i pi) (j pj) -> ... (c pi pj) i j', pi=2, pj=2))
+
+
+def test_generator_cache_is_keyed_on_wavelength_values():
+    """alternating two same-length wavelength sets through FRESH tensors in eval /
+    no_grad must never return the other set's kernels (a recycled address used to hit a stale entry),
+    and the same tensor object passed again must hit without being recomputed."""
+    import gc
+    from eo_vae_amd.dynamic_conv import DynamicConv
+    torch.manual_seed(3)
+    m = DynamicConv(wv_planes=64, embed_dim=32, num_layers=1).eval()
+    sets = [[0.665, 0.56, 0.49], [0.842, 1.61, 2.19]]
+    with torch.no_grad():
+        m._gen_cache.clear()
+        want = []
+        for vals in sets:
+            m.train()
+            want.append([t.clone() for t in m._raw(torch.tensor(vals))])   # uncached (training mode)
+            m.eval()
+        wrong = 0
+        for i in range(200):
+            w = torch.tensor(sets[i % 2])     # fresh tensor every time: addresses get recycled
+            got = m._raw(w)
+            wrong += int(not all(torch.equal(a, b) for a, b in zip(got, want[i % 2])))
+            del w, got
+            if i % 16 == 0:
+                gc.collect()
+        assert wrong == 0
+        # identity fast path + in-place edit of a cached tensor object
+        w = torch.tensor(sets[0])
+        a = m._raw(w)
+        assert m._raw(w)[0] is a[0]
+        w.copy_(torch.tensor(sets[1]))
+        assert torch.equal(m._raw(w)[0], want[1][0])

@@ -436,26 +436,28 @@ def test_trainer_mixed_precision_flag(tmp_path):
     from eo_vae_amd.model import Decoder, Encoder
     from eo_vae_amd.trainer import Trainer
     losses = {}
-    old = ops.CONV_PRECISION
-    try:
-        for prec in ('32-true', 'bf16-mixed'):
-            ops.CONV_PRECISION = 'bf16x3'
-            cfg = O.model_cfg(**{**O.TINY, 'channels': 3})
-            ref = O.build_vae(cfg)
-            O.det_fill(ref, seed=5)
-            m = EOFluxVAE(Encoder(**cfg['encoder']), Decoder(**cfg['decoder']),
-                          EOConsistencyLoss(pixel_weight=1.0, rec_loss_type='char'), freeze_body=False,
-                          base_lr=1e-3, clip_grad=1.0)
-            m.load_state_dict(ref.state_dict(), strict=False)
-            dm = SyntheticDataModule(batch_size=2, modalities=['S2RGB'], target_size=(64, 64), train_steps=3,
-                                     val_steps=1, train_collate_mode='S2RGB', val_collate_mode='S2RGB', seed=7)
-            tr = Trainer(max_steps=3, max_epochs=1, log_every_n_steps=1, precision=prec,
-                         default_root_dir=str(tmp_path / prec), enable_checkpointing=False)
-            assert ops.CONV_PRECISION == ('bf16' if prec == 'bf16-mixed' else 'bf16x3')
-            tr.fit(m, datamodule=dm)
-            losses[prec] = [r['train/loss_total'] for r in tr.history if 'train/loss_total' in r]
-    finally:
-        ops.CONV_PRECISION = old
+    before = ops.CONV_PRECISION
+    for prec in ('bf16-mixed', '32-true'):   # mixed FIRST: it must not leak into the 32-true fit after it
+        cfg = O.model_cfg(**{**O.TINY, 'channels': 3})
+        ref = O.build_vae(cfg)
+        O.det_fill(ref, seed=5)
+        m = EOFluxVAE(Encoder(**cfg['encoder']), Decoder(**cfg['decoder']),
+                      EOConsistencyLoss(pixel_weight=1.0, rec_loss_type='char'), freeze_body=False,
+                      base_lr=1e-3, clip_grad=1.0)
+        m.load_state_dict(ref.state_dict(), strict=False)
+        dm = SyntheticDataModule(batch_size=2, modalities=['S2RGB'], target_size=(64, 64), train_steps=3,
+                                 val_steps=1, train_collate_mode='S2RGB', val_collate_mode='S2RGB', seed=7)
+        tr = Trainer(max_steps=3, max_epochs=1, log_every_n_steps=1, precision=prec,
+                     default_root_dir=str(tmp_path / prec), enable_checkpointing=False)
+        assert tr.conv_precision == ('bf16' if prec == 'bf16-mixed' else ops.DEFAULT_PRECISION)
+        assert ops.CONV_PRECISION == before          # constructing a Trainer changes nothing globally
+        seen = []
+        hook = m.encoder.conv_in.register_forward_hook(lambda *a: seen.append(ops.CONV_PRECISION))
+        tr.fit(m, datamodule=dm)
+        hook.remove()
+        assert set(seen) == {tr.conv_precision}       # ... the mode holds inside fit() ...
+        assert ops.CONV_PRECISION == before          # ... and is restored after it
+        losses[prec] = [r['train/loss_total'] for r in tr.history if 'train/loss_total' in r]
     a, b = losses['32-true'], losses['bf16-mixed']
     assert len(a) == len(b) == 3 and all(np.isfinite(b))
     assert abs(a[0] - b[0]) < 5e-2 * abs(a[0]) and abs(a[-1] - b[-1]) < 1e-1 * abs(a[-1])
