@@ -14,6 +14,6 @@ void eovae_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* eovae_last_error(void) { return g_err; }
-int eovae_abi_version(void) { return 2; }  // 2: eovae_adam_step gained weight_decay
+int eovae_abi_version(void) { return 3; }  // 2: eovae_adam_step gained weight_decay; 3: f16c8 convolution entries
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

@@ -108,9 +108,12 @@ def conv_raw(x, wp, kp, mp, bias, residual, cout, ks, mode, out_scale=1.0):
 #   'f32'    exact fp32 on v_mfma_f32_32x32x2_f32 (csrc/conv_f32.hip)
 #   'bf16x3' split-bf16, 3 bf16 MFMAs per step, fp32-grade (~2^-17)  (csrc/conv_bf16x3.hip)
 #   'bf16'   plain bf16 operands, fp32 accumulate (fast mode; does NOT meet the 1e-3 parity bar)
+#   'f16c8'  f16 product + one block-scaled fp8 product carrying both first-order corrections: 2 MFMA
+#            units per algorithmic product instead of 3, whole-model error 1.2e-4 (csrc/conv_f16c8.hip);
+#            3x3 forward / data gradient with K % 32 == 0, everything else runs as 'bf16x3'
 DEFAULT_PRECISION = os.environ.get('EOVAE_CONV_PRECISION', 'bf16x3')   # the parity path
 CONV_PRECISION = DEFAULT_PRECISION
-_PREC = {'bf16x3': 3, 'bf16': 1}
+_PREC = {'bf16x3': 3, 'bf16': 1, 'f16c8': 3}
 
 
 class precision_scope:
@@ -120,7 +123,7 @@ class precision_scope:
     and backward cannot mix code paths."""
 
     def __init__(self, mode):
-        if mode not in ('f32', 'bf16x3', 'bf16'):
+        if mode not in ('f32', 'bf16x3', 'bf16', 'f16c8'):
             raise ValueError(f'unknown conv precision {mode!r}')
         self.mode = mode
 
@@ -135,15 +138,55 @@ class precision_scope:
         return False
 
 
-def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
-    """3x3 stride-1 conv / data-gradient on the bf16 matrix cores (weight in PyTorch layout)."""
+def _use_f16c8(kreal):
+    return CONV_PRECISION == 'f16c8' and kreal % 32 == 0
+
+
+def absmax_bits(t):
+    """[1] int32 device tensor holding the float bits of max|t| (no host sync): the power-of-two
+    pre-scale of an f16c8 data-gradient call is derived from it inside the kernel."""
+    out = torch.empty(1, dtype=torch.int32, device=t.device)
+    L.check(L.load().eovae_absmax_bits(L.ptr(t), t.numel(), L.ptr(out), L.stream()), 'eovae_absmax_bits')
+    return out
+
+
+def _pack3x3(w4, rows, cols, flip, f16c8):
+    """Pack a [rows][cols][3][3] fp32 layer for the 3x3 kernels (split-bf16 tiles or f16c8 tiles)."""
     lib = L.load()
+    if f16c8:
+        wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(rows, cols, int(flip)), dtype=torch.uint8,
+                         device=w4.device)
+        L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w4), L.ptr(wp), rows, cols, int(flip), 1.0, L.stream()),
+                'eovae_conv3x3_f16c8_pack')
+    else:
+        wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(rows, cols, int(flip)), dtype=torch.bfloat16,
+                         device=w4.device)
+        L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(w4), L.ptr(wp), rows, cols, int(flip), 1.0, L.stream()),
+                'eovae_conv3x3_bf16_pack')
+    return wp
+
+
+def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None):
+    lib = L.load()
+    if f16c8:
+        L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
+                                            L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
+                                            L.stream()), 'eovae_conv3x3_f16c8_fwd')
+    else:
+        L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
+                                           cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], subpix,
+                                           L.stream()), 'eovae_conv3x3_bf16_fwd')
+
+
+def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None):
+    """3x3 stride-1 conv / data-gradient on the 16-bit matrix cores (weight in PyTorch layout).
+    amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode."""
     cout, cin = weight.shape[0], weight.shape[1]
-    wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(cout, cin, int(flip)), dtype=torch.bfloat16,
-                     device=x.device)
-    L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(weight), L.ptr(wp), cout, cin, int(flip), 1.0, L.stream()),
-            'eovae_conv3x3_bf16_pack')
     n, cin_g, h, w = x.shape
+    f8 = _use_f16c8(cin_g)
+    if f8 and flip and amax is None:
+        amax = absmax_bits(x)
+    wp = _pack3x3(weight, cout, cin, flip, f8)
     ho, wo = _out_hw(h, w, mode)
     y = torch.empty(n, cout_gemm, ho, wo, dtype=torch.float32, device=x.device)
     timed = CONV3X3_TIMER is not None
@@ -152,9 +195,7 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip):
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout_gemm * cin_g * 9,
                                          4.0 * (x.numel() + y.numel() + weight.numel()))
         ev0.record()
-    L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
-                                       cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], 0,
-                                       L.stream()), 'eovae_conv3x3_bf16_fwd')
+    _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, amax if flip else None)
     if timed:
         ev1.record()
     return y
@@ -169,16 +210,12 @@ def _subpix_ok(weight):
     return SUBPIX_UPSAMPLE and CONV_PRECISION != 'f32' and weight.shape[0] % 128 == 0
 
 
-def _subpix_packed(weight, flip):
+def _subpix_packed(weight, flip, f16c8=False):
     lib = L.load()
     cout, cin = weight.shape[0], weight.shape[1]
     we = torch.empty(4 * cout, cin, 3, 3, dtype=torch.float32, device=weight.device)
     L.check(lib.eovae_subpix_expand(L.ptr(weight), L.ptr(we), cout, cin, L.stream()), 'eovae_subpix_expand')
-    wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(4 * cout, cin, int(flip)), dtype=torch.bfloat16,
-                     device=weight.device)
-    L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(we), L.ptr(wp), 4 * cout, cin, int(flip), 1.0, L.stream()),
-            'eovae_conv3x3_bf16_pack')
-    return wp
+    return _pack3x3(we, 4 * cout, cin, flip, f16c8)
 
 
 def _down_ok(x, weight):
@@ -187,40 +224,35 @@ def _down_ok(x, weight):
             and x.shape[3] % 2 == 0)
 
 
-def _down_packed(weight, dgrad):
+def _down_packed(weight, dgrad, f16c8=False):
     lib = L.load()
     cout, cin = weight.shape[0], weight.shape[1]
     we = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=weight.device)
     L.check(lib.eovae_down_expand(L.ptr(weight), L.ptr(we), cout, cin, int(dgrad), L.stream()),
             'eovae_down_expand')
     rows, cols = (4 * cin, cout) if dgrad else (cout, 4 * cin)   # as a forward layer [rows][cols][3][3]
-    wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(rows, cols, 0), dtype=torch.bfloat16,
-                     device=weight.device)
-    L.check(lib.eovae_conv3x3_bf16_pack(L.ptr(we), L.ptr(wp), rows, cols, 0, 1.0, L.stream()),
-            'eovae_conv3x3_bf16_pack')
-    return wp
+    return _pack3x3(we, rows, cols, 0, f16c8)
 
 
 def down_conv_s2d(x, weight, bias):
     """pad(0,1,0,1) + 3x3 stride 2 in space-to-depth form (K = 4*Cin gathered at the chunk parity)."""
     n, cin, h, w = x.shape
     cout = weight.shape[0]
-    wp = _down_packed(weight, False)
+    f8 = _use_f16c8(cin)
+    wp = _down_packed(weight, False, f8)
     y = torch.empty(n, cout, h // 2, w // 2, dtype=torch.float32, device=x.device)
-    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), None, L.ptr(y), n, cin, h, w,
-                                            cout, h // 2, w // 2, MODE_NORMAL, _PREC[CONV_PRECISION], 3,
-                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
+    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 3, f8)
     return y
 
 
 def down_conv_s2d_dgrad(dy, weight, h, w):
     n, cout = dy.shape[0], dy.shape[1]
     cin = weight.shape[1]
-    wp = _down_packed(weight, True)
+    f8 = _use_f16c8(cout)
+    wp = _down_packed(weight, True, f8)
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
-    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(dy), L.ptr(wp), None, None, L.ptr(dx), n, cout, h // 2, w // 2,
-                                            cin, h, w, MODE_NORMAL, _PREC[CONV_PRECISION], 4, L.stream()),
-            'eovae_conv3x3_bf16_fwd')
+    _launch3x3(dy, wp, None, None, dx, n, cout, h // 2, w // 2, cin, h, w, MODE_NORMAL, 4, f8,
+               absmax_bits(dy) if f8 else None)
     return dx
 
 
@@ -240,16 +272,15 @@ def down_conv_s2d_wgrad(x, dy, weight, db=None):
 def up_conv_subpix(x, weight, bias):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
-    wp = _subpix_packed(weight, False)
+    f8 = _use_f16c8(cin)
+    wp = _subpix_packed(weight, False, f8)
     y = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
     timed = CONV3X3_TIMER is not None
     if timed:
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
                                          4.0 * (x.numel() + y.numel() + weight.numel()))
         ev0.record()
-    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), None, L.ptr(y), n, cin, h, w,
-                                            cout, 2 * h, 2 * w, MODE_NORMAL, _PREC[CONV_PRECISION], 1,
-                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
+    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8)
     if timed:
         ev1.record()
     return y
@@ -258,16 +289,16 @@ def up_conv_subpix(x, weight, bias):
 def up_conv_subpix_dgrad(dy, weight, h, w):
     n, cout = dy.shape[0], dy.shape[1]
     cin = weight.shape[1]
-    wp = _subpix_packed(weight, True)
+    f8 = _use_f16c8(cout)
+    wp = _subpix_packed(weight, True, f8)
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
     timed = CONV3X3_TIMER is not None
     if timed:
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
                                          4.0 * (dy.numel() + dx.numel() + weight.numel()))
         ev0.record()
-    L.check(L.load().eovae_conv3x3_bf16_fwd(L.ptr(dy), L.ptr(wp), None, None, L.ptr(dx), n, cout, 2 * h, 2 * w,
-                                            cin, h, w, MODE_NORMAL, _PREC[CONV_PRECISION], 2, L.stream()),
-            'eovae_conv3x3_bf16_fwd')
+    _launch3x3(dy, wp, None, None, dx, n, cout, 2 * h, 2 * w, cin, h, w, MODE_NORMAL, 2, f8,
+               absmax_bits(dy) if f8 else None)
     if timed:
         ev1.record()
     return dx

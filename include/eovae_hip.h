@@ -64,6 +64,23 @@ int eovae_conv3x3_bf16_pack(const float* w, void* wp, int Cout, int Cin, int fli
 int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                            float* y, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
                            int mode, int precision, int subpix, void* stream);
+/* "f16c8" variant of the same 3x3 stride-1 convolution (csrc/conv_f16c8.hip): x*w = f16(x)*f16(w) on
+ * v_mfma_f32_32x32x16_f16 plus ONE block-scaled fp8 product (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 =
+ * [x_lo | x_hi] . [w_hi | w_lo]) carrying both first-order corrections: 2 matrix-core units per algorithmic
+ * product instead of bf16x3's 3, whole-model error 1.2e-4 vs the reference's fp32 output (bar 1e-3).
+ * Replaces the same reference call sites as eovae_conv3x3_bf16_fwd (layers.py:29-50, 70-110 via F.conv2d /
+ * its autograd data gradient).  Modes / subpix as eovae_conv3x3_bf16_fwd; the GEMM K channel count must be
+ * a multiple of 32.  Weights: 16 KiB per (tap, 32-channel chunk, 128-co block) + a 16-byte header holding the
+ * float bits of max|w| (set by the packer, read by the kernel for the fp8 block scales).
+ * xamax (nullable): device pointer to the float bits of max|x| (eovae_absmax_bits) for inputs that may sit
+ * outside f16's range (gradients): the loader pre-scales by an exact power of two, the epilogue undoes it. */
+int eovae_absmax_bits(const float* x, size_t n, unsigned* out_bits, void* stream);
+size_t eovae_conv3x3_f16c8_packed_bytes(int Cout, int Cin, int flip);
+int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale,
+                             void* stream);
+int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual,
+                            float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
+                            int Hout, int Wout, int mode, int subpix, void* stream);
 /* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);

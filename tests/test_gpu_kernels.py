@@ -113,10 +113,20 @@ LOWP_CASES = [(2, 32, 32, 16, 16, 'normal'), (1, 128, 128, 64, 64, 'normal'), (2
               (2, 128, 128, 32, 32, 'down'), (1, 256, 256, 24, 40, 'down'), (1, 128, 64, 64, 64, 'down')]
 
 
-@pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2), ('f16c8', 1e-4)])
 @pytest.mark.parametrize('n,cin,cout,h,w,mode', LOWP_CASES)
 def test_conv3x3_split_bf16(n, cin, cout, h, w, mode, precision, tol):
     _lowp_case(n, cin, cout, h, w, 3, mode, precision, tol)
+
+
+@pytest.mark.parametrize('gscale', [2.0 ** -24, 2.0 ** 20])
+@pytest.mark.parametrize('n,cin,cout,h,w,mode', [(1, 128, 128, 64, 64, 'normal'), (1, 256, 256, 32, 32, 'up'),
+                                                 (2, 128, 128, 32, 32, 'down'), (2, 64, 96, 17, 35, 'normal')])
+def test_conv3x3_f16c8_gradient_range(n, cin, cout, h, w, mode, gscale):
+    """f16c8 data gradients far outside f16's range (loss gradients are ~1/numel): the kernel pre-scales
+    dy by the power of two derived from its amax and un-scales in the epilogue, so the result must be
+    exactly as accurate as at unit scale."""
+    _lowp_case(n, cin, cout, h, w, 3, mode, 'f16c8', 1e-4, gscale=gscale)
 
 
 @pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
@@ -127,7 +137,7 @@ def test_conv1x1_split_bf16(n, cin, cout, h, w, precision, tol):
     _lowp_case(n, cin, cout, h, w, 1, 'normal', precision, tol)
 
 
-def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol):
+def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol, gscale=1.0):
     """bf16x3 (hi*hi + hi*lo + lo*hi on the bf16 MFMA) must be fp32-grade: ~2^-17 per product;
     plain bf16 is the flagged fast mode (2^-9) and only has to be sane."""
     from eo_vae_amd import ops
@@ -136,7 +146,7 @@ def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol):
     b = hashed((cout,), 3, 0.1)
     xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yr = ref_conv(xr, wr, br, mode)
-    gy = hashed(tuple(yr.shape), 4, 1.0)
+    gy = hashed(tuple(yr.shape), 4, 1.0) * gscale
     yr.backward(gy)
     old = ops.CONV_PRECISION
     ops.CONV_PRECISION = precision

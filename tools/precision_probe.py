@@ -10,7 +10,7 @@ _, prod = build_pair({}, 31)
 prod.eval()
 wvs = torch.tensor(O.WAVELENGTHS['S2RGB']).cuda()
 x = O.synthetic_batch(2, 3, 256, seed=1234).cuda()
-for prec in ['f32', 'bf16x3', 'bf16']:
+for prec in (sys.argv[1:] or ['f32', 'bf16x3', 'f16c8', 'bf16']):
     ops.CONV_PRECISION = prec
     rec = prod.reconstruct(x, wvs)[:, :, ::8, ::8].double().cpu()
     spat = prod.encode_spatial_normalized(x, wvs)[:, :, ::2, ::2].double().cpu()
