@@ -30,6 +30,7 @@
 // and the weights move through a ring of 4 tap slots in stages of two taps (a ky-row of three taps
 // double buffered would need 96 KiB; with the 78 KiB halo tile of the 16-row block that is over 160 KiB).
 #include "eovae_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -53,23 +54,8 @@ struct ConvCArgs {
   int tiles_x, tiles_y;
   int subpix, creal, cpb;    // as ConvBArgs (conv_bf16x3.hip)
   int xcd_remap;
+  int ntiles;                // tiles x co-blocks walked by the persistent grid
 };
-
-__device__ __forceinline__ int src_index(int mode, int oy0, int ox0, int r, int c, int Hin, int Win) {
-  if (mode == MODE_NORMAL) {
-    const int vy = oy0 + r - 1, vx = ox0 + c - 1;
-    return ((unsigned)vy < (unsigned)Hin && (unsigned)vx < (unsigned)Win) ? vy * Win + vx : -1;
-  } else if (mode == MODE_UP) {
-    const int vy = oy0 + r - 1, vx = ox0 + c - 1;
-    return ((unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win))
-               ? (vy >> 1) * Win + (vx >> 1)
-               : -1;
-  } else {  // MODE_ZINS: adjoint of stride 2 (zero-inserted dy)
-    const int vy = oy0 + r - 2, vx = ox0 + c - 2;
-    const bool ok = (unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win) && !((vy | vx) & 1);
-    return ok ? (vy >> 1) * Win + (vx >> 1) : -1;
-  }
-}
 
 // power of two 2^k as a float, k clamped to the normal range
 __device__ __forceinline__ float pow2f(int k) {
@@ -82,67 +68,114 @@ __device__ __forceinline__ int expo_of_bits(unsigned bits) {
   return e == 0 ? -127 : e - 127;
 }
 
-template <int TH>
+// Tap window of a parity (conv_bf16x3.hip has the derivation): first active tap / number of taps of
+// an axis whose parity bit is pb.
+template <int SUBPIX>
+__device__ __forceinline__ int win0(int pb) {
+  return SUBPIX == 1 ? pb : (SUBPIX == 2 ? 1 - pb : (SUBPIX == 3 ? 1 : (SUBPIX == 4 ? pb : 0)));
+}
+template <int SUBPIX>
+__device__ __forceinline__ int wincnt(int pb) {
+  return SUBPIX == 0 ? 3 : (SUBPIX >= 3 ? 2 - pb : 2);
+}
+
+// One PERSISTENT block per CU walks tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  The unit of the
+// software pipeline is the (tile, 32-channel chunk) pair: while chunk c is multiplied, chunk c+1 -- the
+// next tile's first chunk after a tile's last -- is loaded (stage 0), converted in registers (second to
+// last stage; waves 0-3 before their MFMAs, waves 4-7 after theirs, so that on every SIMD one wave
+// converts while its partner multiplies) and written to the single halo buffer between the two
+// barriers that end the chunk.  Weights arrive by LDS-DMA, two taps per stage, into the other half of
+// a 4-slot ring.  A tile's epilogue runs with the next tile's first chunk already staged.
+// Diagnostic build only (-DEOVAE_C8_STAMP=1, tools/c8_stamps.py): shader-clock stamps per pipeline stage of
+// the first blocks, written to a buffer nothing else reads.  The product build has no stamp code.
+#ifndef EOVAE_C8_STAMP
+#define EOVAE_C8_STAMP 0
+#endif
+#if EOVAE_C8_STAMP
+#define C8_NPT 8
+#define C8_MAXREC 96
+#define C8_NBLK 4
+__device__ unsigned long long c8_stamps[C8_NBLK * 8 * C8_MAXREC * C8_NPT];
+#define C8_STAMP(id)                                                                                          \
+  do {                                                                                                        \
+    if (lane == 0 && blockIdx.x < C8_NBLK && rec < C8_MAXREC)                                                 \
+      c8_stamps[((blockIdx.x * 8 + wave) * C8_MAXREC + rec) * C8_NPT + (id)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define C8_STAMP(id) do {} while (0)
+#endif
+#ifndef EOVAE_C8_ABL
+#define EOVAE_C8_ABL 0   // timing-only experiments: 1 few stores, 2 no halo loads, 4 no conversion, 8 no weight DMA, 16 no MFMAs
+#endif
+template <int TH, int SUBPIX>
 __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   constexpr int NW = 8, TW = 32, BM = 128, KC = 32, NTHR = NW * 64;
   constexpr int XH = TH + 2, XW = TW + 2, NPX = XH * XW;
   constexpr int NI = TH / (NW / 2);             // pixel-row tiles per wave
   constexpr int XF16 = 4 * NPX * 16;            // f16 image: [octet][pixel][8 ch]
   constexpr int XSET = 8 * NPX * 16;            // + fp8 images [lo'|hi'][half][pixel][16 B]
-  constexpr bool XDB = TH == 8;                 // second halo buffer where it fits
   constexpr int WTAP = 16384, WF16 = 8192;
+  // two halo buffers where they fit beside the 4-slot weight ring (8-row tile: 2 x 42.5 + 64 KiB): the staged
+  // chunk is converted straight into the other buffer, no barrier pair and no packed copy in registers
+  constexpr bool XDB = 2 * XSET + 4 * WTAP <= 160 * 1024;
   constexpr int OFF_W = (XDB ? 2 : 1) * XSET;
   constexpr int XTASKS = NPX * 4;               // (pixel, 8-channel octet)
   constexpr int XPT = (XTASKS + NTHR - 1) / NTHR;
+  // The halo loads of the next chunk are issued in 8 groups (one channel of every task each) behind the
+  // MFMAs of taps 0-3 -- a burst of all of them stalled the issuing wave for 3-5 k cycles (TA back-pressure,
+  // tools/c8_stamps.py) -- and the barriers wait with a COUNTED vmcnt that covers the stage's weight DMAs
+  // (issued first) but leaves the groups issued after them in flight.
+  constexpr int LPG = XPT;                      // loads per group
+  constexpr bool KGATHER = SUBPIX == 2 || SUBPIX == 3;  // K channels gathered at a parity
+  constexpr bool MSHUFFLE = SUBPIX == 1 || SUBPIX == 4; // M rows pixel-shuffled on store
   __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_W + 4 * WTAP];
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  int b = blockIdx.x;
-  int cob;
-  if (a.xcd_remap) {  // the ncob blocks sharing one halo tile take consecutive slots of ONE XCD
-    const int xcd = b & 7, q = b >> 3;
-    cob = q % a.ncob;
-    b = (q / a.ncob) * 8 + xcd;
-  } else {
-    cob = b % a.ncob;
-    b /= a.ncob;
-  }
-  const int tx = b % a.tiles_x;
-  b /= a.tiles_x;
-  const int ty = b % a.tiles_y;
-  const int n = b / a.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
+  // readfirstlane: the wave index is uniform, which lets the role branches below be scalar branches
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wco = (wave & 1) * 64, wrow = (wave >> 1) * NI;
   const size_t in_plane = (size_t)a.Hin * a.Win;
-  const bool kgather = a.subpix == 2 || a.subpix == 3;  // K channels gathered at a parity
-  const bool mshuffle = a.subpix == 1 || a.subpix == 4; // M rows pixel-shuffled on store
-  const int xch = kgather ? a.creal : a.Cin;
-  const float* xn = a.x + (size_t)n * xch * in_plane;
-  const int par1 = mshuffle ? cob / a.cpb : 0;
-  auto parity_of = [&](int chunk) { return kgather ? (chunk * KC) / a.creal : par1; };
-  auto win0 = [&](int pb) {  // first active tap of an axis whose parity bit is pb (conv_bf16x3.hip)
-    switch (a.subpix) {
-      case 1: return pb;
-      case 2: return 1 - pb;
-      case 3: return 1;
-      case 4: return pb;
-      default: return 0;
+  const int xch = KGATHER ? a.creal : a.Cin;
+
+  struct Tile { int cob, n, oy0, ox0, par1; };
+  auto decode = [&](int b) {
+    Tile t;
+    if (a.xcd_remap) {  // the ncob blocks sharing one halo tile take consecutive slots of ONE XCD
+      const int xcd = b & 7, q = b >> 3;
+      t.cob = q % a.ncob;
+      b = (q / a.ncob) * 8 + xcd;
+    } else {
+      t.cob = b % a.ncob;
+      b /= a.ncob;
     }
+    const int tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    t.n = b / a.tiles_y;
+    t.oy0 = ty * TH;
+    t.ox0 = tx * TW;
+    t.par1 = MSHUFFLE ? t.cob / a.cpb : 0;
+    return t;
   };
-  auto wincnt = [&](int pb) { return a.subpix == 0 ? 3 : (a.subpix >= 3 ? 2 - pb : 2); };
-  auto ntaps_of = [&](int chunk) {
-    const int par = parity_of(chunk);
-    return wincnt(par >> 1) * wincnt(par & 1);
+  auto parity_of = [&](const Tile& t, int chunk) { return KGATHER ? (chunk * KC) / a.creal : t.par1; };
+  auto ntaps_of = [&](const Tile& t, int chunk) {
+    const int par = parity_of(t, chunk);
+    return wincnt<SUBPIX>(par >> 1) * wincnt<SUBPIX>(par & 1);
   };
-  // t-th active tap of a chunk -> (ky, kx); t is clamped so that a dummy second tap re-reads a real one
-  auto tap_of = [&](int chunk, int t, int& ky, int& kx) {
-    const int par = parity_of(chunk);
-    const int kxc = wincnt(par & 1), nt = wincnt(par >> 1) * kxc;
-    t = t < nt ? t : nt - 1;
-    const int q = kxc == 3 ? t / 3 : (kxc == 2 ? t >> 1 : t);
-    ky = win0(par >> 1) + q;
-    kx = win0(par & 1) + (t - q * kxc);
+  // ti-th active tap of a chunk -> (ky, kx); ti is clamped so that a dummy second tap re-reads a real one
+  auto tap_of = [&](const Tile& t, int chunk, int ti, int& ky, int& kx) {
+    if (SUBPIX == 0) {
+      ti = ti < 9 ? ti : 8;
+      ky = ti / 3;
+      kx = ti - 3 * ky;
+    } else {
+      const int par = parity_of(t, chunk);
+      const int kxc = wincnt<SUBPIX>(par & 1), nt = wincnt<SUBPIX>(par >> 1) * kxc;
+      ti = ti < nt ? ti : nt - 1;
+      const int q = kxc == 2 ? ti >> 1 : ti;
+      ky = win0<SUBPIX>(par >> 1) + q;
+      kx = win0<SUBPIX>(par & 1) + (ti - q * kxc);
+    }
   };
 
   // operand scales.  x: 2^sx puts the tensor's amax at 2^13..2^14 (1 when no amax is given).
@@ -164,128 +197,203 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   const int sc_a = e8m0(-e1 - 12);
   const int sc_b = e8m0(0);
 
+  // ---- halo loader: raw fp32 in xr[][], converted IN PLACE to the packed LDS payload
+  //      (xr[i][0..3] = 8 x f16, [4..5] = 8 x lo' bytes, [6..7] = 8 x hi' bytes)
   float xr[XPT][8];
-  f32x4 wr[2][2];
-
-  // chunk-invariant element offsets of this thread's halo tasks (loads are UNCONDITIONAL from a clamped
-  // address, the validity mask is applied at conversion -- conv_bf16x3.hip explains why)
   unsigned xoff[XPT];
-  bool xok[XPT];
+  unsigned xokm = 0;
+  auto setup_x = [&](const Tile& t) {
+    xokm = 0;
+    int xt = tid;    // laundered: keeps the per-task index math out of the registers that live across the tile loop
+    asm volatile("" : "+v"(xt));
 #pragma unroll
-  for (int i = 0; i < XPT; ++i) {
-    const int t = tid + i * NTHR;
-    const int g = t / NPX, pix = t - g * NPX;
-    const int rr = pix / XW, cc = pix - rr * XW;
-    int si = -1;
-    if (t < XTASKS) {
-      if (kgather) {
-        const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
-        if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout) si = 2 * vy * a.Win + 2 * vx;
-      } else {
-        si = src_index(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+    for (int i = 0; i < XPT; ++i) {
+      const int tk = xt + i * NTHR;
+      const int g = tk / NPX, pix = tk - g * NPX;
+      const int rr = pix / XW, cc = pix - rr * XW;
+      int si = -1;
+      if (tk < XTASKS) {
+        if (KGATHER) {
+          const int vy = t.oy0 + rr - 1, vx = t.ox0 + cc - 1;
+          if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout) si = 2 * vy * a.Win + 2 * vx;
+        } else {   // MODE_NORMAL only (the host routes the other modes to the split-bf16 kernel)
+          const int vy = t.oy0 + rr - 1, vx = t.ox0 + cc - 1;
+          if ((unsigned)vy < (unsigned)a.Hin && (unsigned)vx < (unsigned)a.Win) si = vy * a.Win + vx;
+        }
       }
+      xokm |= (si >= 0 ? 1u : 0u) << i;
+      // BYTE offset: scalar base + 32-bit lane offset is one instruction (saddr form), no 64-bit lane address
+      xoff[i] = 4u * ((unsigned)((tk < XTASKS ? g : 0) * 8) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0));
     }
-    xok[i] = si >= 0;
-    xoff[i] = (unsigned)((t < XTASKS ? g : 0) * 8) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0);
-  }
-  auto load_x = [&](int c0) {
+  };
+  // UNCONDITIONAL loads from clamped addresses; validity is applied at conversion (conv_bf16x3.hip).
+  // Group j = channel j of every task's octet.
+  auto load_x_group = [&](const Tile& t, int c0, int j) __attribute__((always_inline)) {
     int cbase = c0, poff = 0;
-    if (kgather) {
+    if (KGATHER) {
       const int par = c0 / a.creal;
       cbase = c0 - par * a.creal;
       poff = (par >> 1) * a.Win + (par & 1);
     }
-    const float* cb = xn + (size_t)cbase * in_plane + poff;
+    const char* cj = reinterpret_cast<const char*>(a.x + ((size_t)t.n * xch + cbase + j) * in_plane + poff);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float* cj = cb + (size_t)j * in_plane;
-#pragma unroll
-      for (int i = 0; i < XPT; ++i) xr[i][j] = cj[xoff[i]];
-    }
+    for (int i = 0; i < XPT; ++i) xr[i][j] = *reinterpret_cast<const float*>(cj + xoff[i]);
   };
-  auto store_x = [&](int xb) {
-    unsigned char* xsm = smem + (XDB ? xb * XSET : 0);
+  // convert one task's 8 channels and write its three LDS payloads (f16 x 8, lo' x 8, hi' x 8) to buffer xb
+  auto convert_store_x = [&](int xb) __attribute__((always_inline)) {
+    unsigned char* xsm = smem + xb * XSET;
+    int xt = tid;
+    asm volatile("" : "+v"(xt));
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int t = tid + i * NTHR;
-      if (t < XTASKS) {
-        const int g = t / NPX, pix = t - g * NPX;
-        f16x8 hi;
-        float lo[8], v[8];
+      const int tk = xt + i * NTHR;
+      const float sm = ((xokm >> i) & 1) ? xs : 0.f;   // validity folded into the scale
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      float v[8], lo[8];
+      int pk[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[j] = xok[i] ? xr[i][j] * xs : 0.f;
-          const _Float16 hh = (_Float16)v[j];
-          hi[j] = hh;
-          lo[j] = (v[j] - (float)hh) * 4096.f;
-        }
-        i32x2 l8, h8;
-        l8[0] = __builtin_amdgcn_cvt_pk_bf8_f32(lo[0], lo[1], 0, false);
-        l8[0] = __builtin_amdgcn_cvt_pk_bf8_f32(lo[2], lo[3], l8[0], true);
-        l8[1] = __builtin_amdgcn_cvt_pk_bf8_f32(lo[4], lo[5], 0, false);
-        l8[1] = __builtin_amdgcn_cvt_pk_bf8_f32(lo[6], lo[7], l8[1], true);
-        h8[0] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
-        h8[0] = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h8[0], true);
-        h8[1] = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
-        h8[1] = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h8[1], true);
-        *reinterpret_cast<f16x8*>(xsm + g * (NPX * 16) + pix * 16) = hi;
+      for (int j = 0; j < 8; j += 2) {
+        v[j] = xr[i][j] * sm;
+        v[j + 1] = xr[i][j + 1] * sm;
+        f16x2 hh;
+        hh[0] = (_Float16)v[j];
+        hh[1] = (_Float16)v[j + 1];
+        pk[j >> 1] = __builtin_bit_cast(int, hh);
+        lo[j] = v[j] - (float)hh[0];
+        lo[j + 1] = v[j + 1] - (float)hh[1];
+      }
+      // lo' = e5m2(lo * 2^12): the conversion instruction divides by its scale operand
+      s16x2 l0 = {0, 0}, l1 = {0, 0};
+      l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+      l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+      l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+      l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+      int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+      h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
+      int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
+      h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h1, true);
+      if (tk < XTASKS) {
+        const int g = tk / NPX, pix = tk - g * NPX;
+        i32x4 hv;
+        hv[0] = pk[0]; hv[1] = pk[1]; hv[2] = pk[2]; hv[3] = pk[3];
+        i32x2 lv, uv;
+        lv[0] = __builtin_bit_cast(int, l0); lv[1] = __builtin_bit_cast(int, l1);
+        uv[0] = h0; uv[1] = h1;
+        *reinterpret_cast<i32x4*>(xsm + g * (NPX * 16) + pix * 16) = hv;
         unsigned char* p8 = xsm + XF16 + ((g >> 1) * NPX + pix) * 16 + (g & 1) * 8;
-        *reinterpret_cast<i32x2*>(p8) = l8;                      // part 0: lo'
-        *reinterpret_cast<i32x2*>(p8 + 2 * NPX * 16) = h8;       // part 1: hi'
+        *reinterpret_cast<i32x2*>(p8) = lv;                      // part 0: lo'
+        *reinterpret_cast<i32x2*>(p8 + 2 * NPX * 16) = uv;       // part 1: hi'
       }
     }
   };
-  // weights of one stage = taps t0, t0+1 of a chunk (a missing second tap re-reads the first)
-  auto load_w = [&](int chunk, int t0) {
+  auto convert_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const bool ok = (xokm >> i) & 1;
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      float lo[8], v[8];
+      int pk[4];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        v[j] = ok ? xr[i][j] * xs : 0.f;
+        v[j + 1] = ok ? xr[i][j + 1] * xs : 0.f;
+        f16x2 hh;
+        hh[0] = (_Float16)v[j];
+        hh[1] = (_Float16)v[j + 1];
+        lo[j] = (v[j] - (float)hh[0]) * 4096.f;
+        lo[j + 1] = (v[j + 1] - (float)hh[1]) * 4096.f;
+        pk[j >> 1] = __builtin_bit_cast(int, hh);
+      }
+      int l0 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[0], lo[1], 0, false);
+      l0 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[2], lo[3], l0, true);
+      int l1 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[4], lo[5], 0, false);
+      l1 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[6], lo[7], l1, true);
+      int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+      h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
+      int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
+      h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h1, true);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xr[i][k] = __builtin_bit_cast(float, pk[k]);
+      xr[i][4] = __builtin_bit_cast(float, l0);
+      xr[i][5] = __builtin_bit_cast(float, l1);
+      xr[i][6] = __builtin_bit_cast(float, h0);
+      xr[i][7] = __builtin_bit_cast(float, h1);
+    }
+  };
+  auto store_x = [&]() __attribute__((always_inline)) {
+    // laundered lane index: the LDS addresses below are loop invariant, and hoisted out of the tile loop
+    // they were spilled and reloaded one by one (scratch load + wait per ds_write) between the two barriers
+    int xt = tid;
+    asm volatile("" : "+v"(xt));
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int tk = xt + i * NTHR;
+      if (tk < XTASKS) {
+        const int g = tk / NPX, pix = tk - g * NPX;
+        f32x4 hv;
+        hv[0] = xr[i][0]; hv[1] = xr[i][1]; hv[2] = xr[i][2]; hv[3] = xr[i][3];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 lv, uv;
+        lv[0] = xr[i][4]; lv[1] = xr[i][5];
+        uv[0] = xr[i][6]; uv[1] = xr[i][7];
+        *reinterpret_cast<f32x4*>(smem + g * (NPX * 16) + pix * 16) = hv;
+        unsigned char* p8 = smem + XF16 + ((g >> 1) * NPX + pix) * 16 + (g & 1) * 8;
+        *reinterpret_cast<f32x2*>(p8) = lv;                      // part 0: lo'
+        *reinterpret_cast<f32x2*>(p8 + 2 * NPX * 16) = uv;       // part 1: hi'
+      }
+    }
+  };
+  // weights of one stage (taps t0, t0+1 of a chunk) by LDS-DMA into ring half `half`: a wave moves 2 KiB
+  // of each 16 KiB tap tile (2 instructions of 64 lanes x 16 B, LDS image = global image)
+  auto dma_w = [&](const Tile& t, int chunk, int t0, int half) __attribute__((always_inline)) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       int ky, kx;
-      tap_of(chunk, t0 + tt, ky, kx);
-      const size_t tile = ((size_t)((ky * 3 + kx) * a.nchunk + chunk) * a.ncob + cob);
+      tap_of(t, chunk, t0 + tt, ky, kx);
+      const unsigned char* src = a.wp + ((size_t)((ky * 3 + kx) * a.nchunk + chunk) * a.ncob + t.cob) * WTAP;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        wr[tt][u] = *reinterpret_cast<const f32x4*>(a.wp + tile * WTAP + (tid + u * NTHR) * 16);
+      for (int u = 0; u < 2; ++u) {
+        const int piece = (wave * 2 + u) * 1024;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
+            (__attribute__((address_space(3))) void*)(smem + OFF_W + (half * 2 + tt) * WTAP + piece), 16, 0, 0);
+      }
     }
-  };
-  auto store_w = [&](int slot0) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        *reinterpret_cast<f32x4*>(smem + OFF_W + (slot0 + tt) * WTAP + (tid + u * NTHR) * 16) = wr[tt][u];
   };
 
   f32x16 acc[2][NI];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  };
 
-  load_x(0);
-  load_w(0, 0);
-  store_x(0);
-  store_w(0);
-  __syncthreads();
+  // Per-lane LDS byte offsets of the fragment reads; everything else about a read is a compile-time
+  // immediate (tap, row tile, k-step), so one VGPR per image serves every ds_read of the kernel.
+  const unsigned xl16 = (unsigned)(h * (NPX * 16) + (wrow * XW + r) * 16);            // f16 halo image
+  const unsigned xl8 = (unsigned)(XF16 + (h * 2) * (NPX * 16) + (wrow * XW + r) * 16); // fp8 halo images
+  const unsigned wl16 = (unsigned)(OFF_W + h * (BM * 16) + (wco + r) * 16);            // f16 weight image
+  const unsigned wl8 = (unsigned)(OFF_W + WF16 + (h * 2) * (BM * 16) + (wco + r) * 16); // fp8 weight images
 
-  // one tap: 2 co-tiles x NI pixel-row tiles x (2 f16 MFMAs + 1 scaled fp8 MFMA)
-  auto compute_tap = [&](const unsigned char* wb, const unsigned char* xb, int ky, int kx)
-      __attribute__((always_inline)) {
-    const int arow = (wco + r) * 16;
-    // --- pass 1: f16 main term.  Fragment of k-step s = octet 2s + h.
-    {
+  // one tap: 2 co-tiles x NI pixel-row tiles x (2 f16 MFMAs + 1 scaled fp8 MFMA).  wslot = byte offset of
+  // the tap's ring slot; (ky, kx) are compile-time constants on the plain path.
+  auto compute_tap = [&](unsigned wslot, unsigned xsel, int ky, int kx) __attribute__((always_inline)) {
+    const unsigned tapoff = (unsigned)((ky * XW + kx) * 16) + xsel;
+    {  // pass 1: f16 main term.  Fragment of k-step s = octet 2s + h.
       f16x8 ah[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-          ah[i][s] = *reinterpret_cast<const f16x8*>(wb + (2 * s + h) * (BM * 16) + arow + i * 512);
+          ah[i][s] = *reinterpret_cast<const f16x8*>(smem + (wl16 + wslot) + (2 * s) * (BM * 16) + i * 512);
       auto xfrag = [&](int j, f16x8 (&f)[2]) __attribute__((always_inline)) {
-        const int pix = (wrow + j + ky) * XW + r + kx;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-          f[s] = *reinterpret_cast<const f16x8*>(xb + (2 * s + h) * (NPX * 16) + pix * 16);
+          f[s] = *reinterpret_cast<const f16x8*>(smem + (xl16 + tapoff) + (2 * s) * (NPX * 16) + j * (XW * 16));
       };
       f16x8 bh[2], nh[2];
       xfrag(0, bh);
@@ -301,19 +409,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
         bh[1] = nh[1];
       }
     }
-    // --- pass 2: both correction terms in one K = 64 block-scaled product.
-    {
+    {  // pass 2: both correction terms in one K = 64 block-scaled product
       i32x8 a8[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const unsigned char* p = wb + WF16 + (h * 2) * (BM * 16) + arow + i * 512;
+        const unsigned char* p = smem + (wl8 + wslot) + i * 512;
         const i32x4 q0 = *reinterpret_cast<const i32x4*>(p);
         const i32x4 q1 = *reinterpret_cast<const i32x4*>(p + BM * 16);
         a8[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
       auto xfrag8 = [&](int j) __attribute__((always_inline)) {
-        const int pix = (wrow + j + ky) * XW + r + kx;
-        const unsigned char* p = xb + XF16 + ((h * 2) * NPX + pix) * 16;
+        const unsigned char* p = smem + (xl8 + tapoff) + j * (XW * 16);
         const i32x4 q0 = *reinterpret_cast<const i32x4*>(p);
         const i32x4 q1 = *reinterpret_cast<const i32x4*>(p + NPX * 16);
         return (i32x8)__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -331,100 +437,209 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     }
   };
 
-  int q = 0;  // global stage counter: ring half (q & 1) holds the stage being multiplied
-  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    const int nt = ntaps_of(chunk), ns = (nt + 1) >> 1;
-    const unsigned char* xb = smem + (XDB ? (chunk & 1) * XSET : 0);
-    for (int s = 0; s < ns; ++s, ++q) {
-      const bool last_stage = s == ns - 1;
-      const bool has_next = !(last_stage && chunk + 1 == a.nchunk);
-      if (has_next) {
-        if (last_stage) load_w(chunk + 1, 0); else load_w(chunk, 2 * s + 2);
-      }
-      if (s == 0 && chunk + 1 < a.nchunk) load_x((chunk + 1) * KC);
-
-      const unsigned char* wb = smem + OFF_W + (q & 1) * 2 * WTAP;
-      {
-        int ky, kx;
-        tap_of(chunk, 2 * s, ky, kx);
-        compute_tap(wb, xb, ky, kx);
-        if (2 * s + 1 < nt) {  // uniform
-          tap_of(chunk, 2 * s + 1, ky, kx);
-          compute_tap(wb + WTAP, xb, ky, kx);
-        }
-      }
-
-      if (has_next) store_w(((q + 1) & 1) * 2);   // other ring half: last read a barrier ago
-      if (last_stage && chunk + 1 < a.nchunk) {
-        if (!XDB) __syncthreads();                // one buffer: every wave is done with this chunk's tile
-        store_x((chunk + 1) & 1);
-      }
-      __syncthreads();
+  // Epilogue of one tile: as conv_bf16x3.hip (batched unconditional bias / residual loads, plain stores on
+  // full tiles), plus the exact power-of-two un-scaling of a scaled input.
+  auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
+    const int ox = t.ox0 + r;
+    const bool okx = ox < a.Wout;
+    const int chans = MSHUFFLE ? a.creal : a.Cout;
+    const int co_blk = (MSHUFFLE ? (t.cob - t.par1 * a.cpb) : t.cob) * BM;
+    const int co_base = co_blk + wco + 4 * h;
+    const int py = t.par1 >> 1, px = t.par1 & 1;
+    const size_t out_plane = MSHUFFLE ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
+    float* yn = a.y + (size_t)t.n * chans * out_plane;
+    const float* rn = a.res ? a.res + (size_t)t.n * chans * out_plane : nullptr;
+    unsigned rowoff[NI];
+    bool rowok[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int oy = t.oy0 + wrow + j;
+      rowok[j] = okx && oy < a.Hout;
+      const int oyc = oy < a.Hout ? oy : a.Hout - 1, oxc = okx ? ox : a.Wout - 1;
+      rowoff[j] = MSHUFFLE ? (unsigned)((2 * oyc + py) * (2 * a.Wout) + 2 * oxc + px)
+                           : (unsigned)(oyc * a.Wout + oxc);
     }
-  }
-
-  // Epilogue: as conv_bf16x3.hip (batched unconditional bias / residual loads, plain stores on full
-  // tiles), plus the exact power-of-two un-scaling of a scaled input.
-  const int ox = ox0 + r;
-  const bool okx = ox < a.Wout;
-  const int chans = mshuffle ? a.creal : a.Cout;
-  const int co_blk = (mshuffle ? (cob - par1 * a.cpb) : cob) * BM;
-  const int co_base = co_blk + wco + 4 * h;
-  const int py = par1 >> 1, px = par1 & 1;
-  const size_t out_plane = mshuffle ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
-  float* yn = a.y + (size_t)n * chans * out_plane;
-  const float* rn = a.res ? a.res + (size_t)n * chans * out_plane : nullptr;
-  unsigned rowoff[NI];
-  bool rowok[NI];
+    auto body = [&](auto full_t) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int oy = oy0 + wrow + j;
-    rowok[j] = okx && oy < a.Hout;
-    const int oyc = oy < a.Hout ? oy : a.Hout - 1, oxc = okx ? ox : a.Wout - 1;
-    rowoff[j] = mshuffle ? (unsigned)((2 * oyc + py) * (2 * a.Wout) + 2 * oxc + px)
-                         : (unsigned)(oyc * a.Wout + oxc);
-  }
-  auto epilogue = [&](auto full_t) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_t)::value;
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int qq = 0; qq < 4; ++qq) {
+          if ((EOVAE_C8_ABL & 1) && (i || qq)) {   // timing-only: keep the values alive, store 1/8 of them
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        float bias4[4], rv[4][NI];
-        int coc[4];
-        bool cok[4];
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int co = co_base + i * 32 + k + 8 * qq;
-          cok[k] = FULL || co < chans;
-          coc[k] = cok[k] ? co : chans - 1;
-          bias4[k] = a.bias ? a.bias[coc[k]] : 0.f;
-        }
-        if (rn) {
+              for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(acc[i][j][4 * qq + k]));
+            continue;
+          }
+          float bias4[4], rv[4][NI];
+          int coc[4];
+          bool cok[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int co = co_base + i * 32 + k + 8 * qq;
+            cok[k] = FULL || co < chans;
+            coc[k] = cok[k] ? co : chans - 1;
+            bias4[k] = a.bias ? a.bias[coc[k]] : 0.f;
+          }
+          if (rn) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int j = 0; j < NI; ++j) rv[k][j] = rn[(size_t)coc[k] * out_plane + rowoff[j]];
+          }
+          float v[4][NI];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) rv[k][j] = rn[(size_t)coc[k] * out_plane + rowoff[j]];
+            for (int j = 0; j < NI; ++j) {
+              v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k];
+              if (rn) v[k][j] += rv[k][j];
+              if (!FULL) asm volatile("" : "+v"(v[k][j]));
+            }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              if (FULL || (cok[k] && rowok[j])) yn[(size_t)coc[k] * out_plane + rowoff[j]] = v[k][j];
         }
-        float v[4][NI];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k];
-            if (rn) v[k][j] += rv[k][j];
-            if (!FULL) asm volatile("" : "+v"(v[k][j]));
-          }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            if (FULL || (cok[k] && rowok[j])) yn[(size_t)coc[k] * out_plane + rowoff[j]] = v[k][j];
       }
-    }
+    };
+    const bool full_tile = t.oy0 + TH <= a.Hout && t.ox0 + TW <= a.Wout && co_blk + BM <= chans;
+    if (full_tile) body(std::true_type{}); else body(std::false_type{});
   };
-  const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && co_blk + BM <= chans;
-  if (full_tile) epilogue(std::true_type{}); else epilogue(std::false_type{});
+
+  // Workgroup barrier that publishes LDS writes and the stage's landed weight DMAs: the wave's INFLIGHT
+  // youngest vector-memory operations (halo loads issued after the DMAs) are left in flight.
+  auto stage_barrier = [&](auto inflight) __attribute__((always_inline)) {
+    constexpr int INFLIGHT = decltype(inflight)::value;
+    static_assert(INFLIGHT >= 0 && INFLIGHT < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  using IC0 = std::integral_constant<int, 0>;
+
+  // ------------------------------------------------------------------ pipeline
+  int tile = blockIdx.x;
+  if (tile >= a.ntiles) return;
+  Tile cur = decode(tile);
+  setup_x(cur);
+  dma_w(cur, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) load_x_group(cur, 0, j);
+  if (XDB) {
+    convert_store_x(0);
+  } else {
+    convert_x();
+    store_x();
+  }
+  zero_acc();
+  stage_barrier(IC0{});
+  int xbuf = 0;   // halo buffer of the chunk being multiplied (XDB)
+
+  int q = 0;  // global stage counter: ring half (q & 1) holds the stage being multiplied
+#if EOVAE_C8_STAMP
+  int rec = 0;
+#endif
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const bool has_next_tile = tile + (int)gridDim.x < a.ntiles;
+    Tile nxt = cur;
+    if (has_next_tile) nxt = decode(tile + gridDim.x);
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      const bool last_chunk = chunk + 1 == a.nchunk;
+      const bool have_nx = !last_chunk || has_next_tile;       // is there a chunk to stage behind this one
+      if (last_chunk && has_next_tile) setup_x(nxt);            // this tile's offsets are not needed any more
+      const int nt = SUBPIX == 0 ? 9 : ntaps_of(cur, chunk), ns = (nt + 1) >> 1;
+      const int cs = ns >= 3 ? ns - 2 : ns - 1;                 // stage that converts the staged chunk
+      const Tile& xt_tile = last_chunk ? nxt : cur;             // where the staged chunk comes from
+      const int xc0 = last_chunk ? 0 : (chunk + 1) * KC;
+#pragma unroll
+      for (int s = 0; s < (SUBPIX == 0 ? 5 : 2); ++s) {
+        if (SUBPIX != 0 && s >= ns) break;
+        const bool last_stage = s == ns - 1;
+        C8_STAMP(0);
+        // weights of the following stage (this chunk, next chunk, or the next tile's first chunk)
+        // (waves 0-3 issue them before their first tap, waves 4-7 behind it: eight waves issuing ~65-cycle DMA
+        // instructions at once left the matrix pipes idle at the top of every stage)
+        auto stage_dma = [&]() __attribute__((always_inline)) {
+          if (EOVAE_C8_ABL & 8) return;
+          if (!last_stage) dma_w(cur, chunk, 2 * s + 2, (q + 1) & 1);
+          else if (!last_chunk) dma_w(cur, chunk + 1, 0, (q + 1) & 1);
+          else if (has_next_tile) dma_w(nxt, 0, 0, (q + 1) & 1);
+        };
+        if (wave < 4) stage_dma();
+        // waves 0-3 convert BEFORE their MFMAs, waves 4-7 after theirs: on every SIMD one wave converts
+        // (VALU) while its partner multiplies
+        if (SUBPIX != 0 && ns == 1 && have_nx) {   // single-stage chunks (stride-2 forms): loaded and converted at once
+#pragma unroll
+          for (int j = 0; j < 8; ++j) load_x_group(xt_tile, xc0, j);
+        }
+        if (!(EOVAE_C8_ABL & 4)) if (s == cs && have_nx && wave < 4) {
+          if (XDB) convert_store_x(xbuf ^ 1); else convert_x();
+        }
+        C8_STAMP(1);
+        const unsigned wslot = (unsigned)((q & 1) * 2 * WTAP);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          if (2 * s + tt < nt) {   // uniform
+            if (!(EOVAE_C8_ABL & 16)) {
+              int ky, kx;
+              tap_of(cur, chunk, 2 * s + tt, ky, kx);
+              compute_tap(wslot + tt * WTAP, XDB ? (unsigned)(xbuf * XSET) : 0u, ky, kx);
+            }
+            if (tt == 0 && wave >= 4) stage_dma();
+            // halo groups of the staged chunk: two behind each of the taps 0..3; chunks with fewer taps
+            // issue what is left behind their last tap
+            if (!(EOVAE_C8_ABL & 2)) if (have_nx) {
+              const int t = 2 * s + tt;
+              if (SUBPIX == 0) {
+                if (t < 4) { load_x_group(xt_tile, xc0, 2 * t); load_x_group(xt_tile, xc0, 2 * t + 1); }
+              } else if (ns == 2 && s == 0) {   // conversion is in stage 1: everything behind taps 0 and 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) load_x_group(xt_tile, xc0, 4 * tt + j);
+              }
+            }
+          }
+        }
+        C8_STAMP(2);
+        if (!(EOVAE_C8_ABL & 4)) if (s == cs && have_nx && wave >= 4) {
+          if (XDB) convert_store_x(xbuf ^ 1); else convert_x();
+        }
+        C8_STAMP(3);
+        if (!XDB && last_stage && have_nx) {
+          stage_barrier(IC0{});     // every wave is done with this chunk's halo tile
+          C8_STAMP(4);
+          store_x();
+          C8_STAMP(5);
+        }
+        C8_STAMP(6);
+        // plain path: stages 0 and 1 each issued 4 groups behind their DMAs
+        if (SUBPIX == 0 && s < 2 && !(EOVAE_C8_ABL & 2)) {
+          if (have_nx) stage_barrier(std::integral_constant<int, 4 * LPG>{}); else stage_barrier(IC0{});
+        } else {
+          stage_barrier(IC0{});
+        }
+        C8_STAMP(7);
+#if EOVAE_C8_STAMP
+        ++rec;
+#endif
+        ++q;
+      }
+      if (have_nx) xbuf ^= 1;
+    }
+#if EOVAE_C8_STAMP
+    C8_STAMP(0);
+#endif
+    epilogue_tile(cur);
+    zero_acc();
+#if EOVAE_C8_STAMP
+    C8_STAMP(7);
+    ++rec;
+#endif
+    cur = nxt;
+  }
 }
 
 // max |x| as float bits (a non-negative float orders like its bit pattern), atomically into *out
@@ -498,6 +713,12 @@ __global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __
 
 extern "C" {
 
+#if EOVAE_C8_STAMP
+int eovae_debug_c8_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(c8_stamps), bytes < sizeof(c8_stamps) ? bytes : sizeof(c8_stamps));
+}
+#endif
+
 // *out_bits = float bits of max |x[i]| (0 for an all-zero tensor); out_bits is device memory
 int eovae_absmax_bits(const float* x, size_t n, unsigned* out_bits, void* stream) {
   EOVAE_CHECK_ARG(x && out_bits && n > 0, "absmax_bits: bad argument");
@@ -554,8 +775,8 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
                             int Wout, int mode, int subpix, void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_f16c8_fwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_f16c8_fwd: bad shape");
-  EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP || mode == MODE_ZINS,
-                  "conv3x3_f16c8_fwd: mode %d unsupported", mode);
+  EOVAE_CHECK_ARG(mode == MODE_NORMAL, "conv3x3_f16c8_fwd: mode %d unsupported (stride-1 'normal' layers and the "
+                  "sub-pixel / space-to-depth forms only)", mode);
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 4, "conv3x3_f16c8_fwd: subpix %d", subpix);
   ConvCArgs a;
   a.x = x; a.wp = (const unsigned char*)wp; a.bias = bias; a.res = residual; a.y = y; a.xamax = xamax;
@@ -589,18 +810,41 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   a.tiles_x = cdiv(Wout, 32);
   hipStream_t st = (hipStream_t)stream;
   auto xcd_ok = [&](long long tiles) { return (a.ncob > 1 && tiles % 8 == 0) ? 1 : 0; };
-  const long long blocks16 = (long long)N * cdiv(Hout, 16) * a.tiles_x * a.ncob;
-  if (blocks16 >= 512) {   // 16-row tiles while they still give every CU two blocks
-    a.tiles_y = cdiv(Hout, 16);
-    a.xcd_remap = xcd_ok((long long)N * a.tiles_y * a.tiles_x);
-    hipLaunchKernelGGL((conv3x3_f16c8_kernel<16>), dim3((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob)), dim3(512),
-                       0, st, a);
-  } else {
-    a.tiles_y = cdiv(Hout, 8);
-    a.xcd_remap = xcd_ok((long long)N * a.tiles_y * a.tiles_x);
-    hipLaunchKernelGGL((conv3x3_f16c8_kernel<8>), dim3((unsigned)(N * a.tiles_y * a.tiles_x * a.ncob)), dim3(512),
-                       0, st, a);
+  static int n_cu = 0;   // one persistent block per CU (142 KiB of LDS each)
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      eovae_set_error("conv3x3_f16c8_fwd: cannot query the device");
+      return EOVAE_ERR_LAUNCH;
+    }
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    n_cu -= n_cu % 8;   // keeps  tile = blockIdx.x + k * gridDim.x  on one XCD (dealt round-robin)
+    if (n_cu < 8) n_cu = 8;
   }
+  // 16-row tiles while they still give every CU two tiles, else 8-row tiles
+  const long long blocks16 = (long long)N * cdiv(Hout, 16) * a.tiles_x * a.ncob;
+  static const char* th_env = getenv("EOVAE_C8_TH");   // experiment hook: force the tile height
+  // 8-row tiles only: the 16-row tile (half the weight traffic per MFMA) needs 128 accumulator + 40 staging
+  // registers per lane and spilled into the loop
+  const bool th16 = false;
+  (void)th_env; (void)blocks16;
+  a.tiles_y = cdiv(Hout, th16 ? 16 : 8);
+  const long long sp_tiles = (long long)N * a.tiles_y * a.tiles_x;
+  a.xcd_remap = xcd_ok(sp_tiles);
+  EOVAE_CHECK_ARG(sp_tiles * a.ncob < (1LL << 30), "conv3x3_f16c8_fwd: too many tiles");
+  a.ntiles = (int)(sp_tiles * a.ncob);
+  const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(512);
+#define EOVAE_LAUNCH_C8(TH)                                                                                   \
+  switch (subpix) {                                                                                           \
+    case 0: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0>), grid, blk, 0, st, a); break;                    \
+    case 1: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 1>), grid, blk, 0, st, a); break;                    \
+    case 2: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 2>), grid, blk, 0, st, a); break;                    \
+    case 3: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 3>), grid, blk, 0, st, a); break;                    \
+    default: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 4>), grid, blk, 0, st, a); break;                   \
+  }
+  EOVAE_LAUNCH_C8(8)
+#undef EOVAE_LAUNCH_C8
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_fwd");
   return EOVAE_OK;
 }

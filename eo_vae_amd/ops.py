@@ -183,7 +183,7 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None):
     amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode."""
     cout, cin = weight.shape[0], weight.shape[1]
     n, cin_g, h, w = x.shape
-    f8 = _use_f16c8(cin_g)
+    f8 = _use_f16c8(cin_g) and mode == MODE_NORMAL
     if f8 and flip and amax is None:
         amax = absmax_bits(x)
     wp = _pack3x3(weight, cout, cin, flip, f8)
