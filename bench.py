@@ -35,6 +35,44 @@ PEAK_BF16_MFMA = 2500e12         # MI355X_MICROARCH.md: dense bf16 MFMA peak (no
 PEAK_HBM = 8.0e12
 
 
+def csrc_digest():
+    """sha256 over the kernel sources: identifies the build a PMC measurement belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'eo_vae_amd', 'csrc', '*'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC fold (tools/pmc_traffic.sh runs the
+    SEPARATE rocprofv3 --pmc passes; this run cannot measure them itself).  The number is only quoted when
+    the fold was taken on THIS build of the kernels (same digest of eo_vae_amd/csrc); otherwise traffic is
+    null and the source says why -- a stale file is never passed off as a measurement."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        k = d.get('kernels', {}).get(kernel)
+        if k is None:
+            continue
+        src = {'file': os.path.relpath(f, ROOT), 'csrc_digest': d.get('csrc_digest'), 'build_digest': csrc_digest(),
+               'fetch_bytes_raw': k.get('fetch_bytes_raw_per_launch'), 'write_bytes': k.get('write_bytes_per_launch'),
+               'note': 'FETCH_SIZE x2 (gfx950 correction, calibrated for 16-B/lane streams; halo loads are dword/lane, '
+                       'so the true figure lies between raw and corrected)'}
+        if d.get('csrc_digest') == src['build_digest']:
+            return k['traffic_bytes_per_launch_corrected'], src
+        src['stale'] = 'kernel sources changed since this fold was measured'
+        return None, src
+    return None, {'file': None, 'note': 'no PMC fold for this kernel under profiles/'}
+
+
 def build_model(channels, kl_weight=1e-6, msssim=False):
     from eo_vae_amd.autoencoder import EOFluxVAE
     from eo_vae_amd.losses import EOConsistencyLoss
@@ -210,19 +248,21 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         ips = args.batch * world * args.steps / elapsed
         k_ms, k_flops, k_n = timer.totals()
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
-            with open(os.path.join(ROOT, 'profiles', 'r01i_pmc_hbm_traffic.json')) as f:
-                traffic = json.load(f)['kernels']['conv3x3_bf16_kernel']['traffic_bytes_per_launch_corrected']
-        except Exception:
-            pass
+        prec = ops.CONV_PRECISION
+        traffic, traffic_source = pmc_traffic('conv3x3_f16c8_kernel' if prec == 'f16c8' else 'conv3x3_bf16_kernel')
         achieved = k_flops / (k_ms * 1e-3) if k_ms > 0 else 0.0
         r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / args.batch)  # img/s per GPU at the HBM roof
         f_img = F_STEP_PER_IMG.get(C, 2.69e12)
-        prec = ops.CONV_PRECISION
         if prec == 'f32':
             peak, kname, dtype = PEAK_FP32_MFMA, 'conv_fwd_kernel<3,1,8> (3x3 conv fwd + data-grad)', 'f32'
             path = 'fp32-input MFMA implicit GEMM (exact fp32)'
+        elif prec == 'f16c8':
+            peak, dtype = PEAK_BF16_MFMA, 'f16c8'
+            kname = 'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)'
+            path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) on v_mfma_f32_32x32x16_f16 + ONE K-concatenated '
+                    'block-scaled fp8 product [x_lo|x_hi].[w_hi|w_lo] on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 '
+                    'accumulate (~1e-5 per product; 2 MFMA units per algorithmic product => frac <= 1/2); weight '
+                    'gradients, 1x1 convolutions and attention stay split-bf16 (3 units)')
         else:
             peak = PEAK_BF16_MFMA
             kname = 'conv3x3_bf16_kernel (3x3 conv fwd + data-grad, split-bf16 operands)'
@@ -247,7 +287,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': round(achieved / 1e12, 2), 'peak': peak / 1e12,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'traffic': traffic if prec != 'f32' else None,
+                         'traffic': traffic if prec != 'f32' else None, 'traffic_source': traffic_source,
                          'algorithmic_bytes_per_launch': round(timer.bytes_total() / max(k_n, 1)),
                          'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},

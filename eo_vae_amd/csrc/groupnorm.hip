@@ -180,8 +180,10 @@ template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ stats, const float* __restrict__ gm,
-    const float* __restrict__ dx_add, float* __restrict__ dx, int C, int HW, int cpg, int chunks) {
+    const float* __restrict__ dx_add, float* __restrict__ dx, int C, int HW, int cpg, int chunks,
+    unsigned* __restrict__ amax_bits) {
   const int plane = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  float amax = 0.f;   // max |dx| of this block (only reported when amax_bits is given)
   const int c = plane % C, n = plane / C;
   const int ng = n * (C / cpg) + c / cpg;
   const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
         float4 o;
         o.x = elem(xv.x, dv.x, av.x); o.y = elem(xv.y, dv.y, av.y);
         o.z = elem(xv.z, dv.z, av.z); o.w = elem(xv.w, dv.w, av.w);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(dx + base + i) = o;
       }
     } else {
@@ -220,12 +223,24 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
         float4 o;
         o.x = elem(xv.x, dv.x, 0.f); o.y = elem(xv.y, dv.y, 0.f);
         o.z = elem(xv.z, dv.z, 0.f); o.w = elem(xv.w, dv.w, 0.f);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(dx + base + i) = o;
       }
     }
   } else {
-    for (int i = beg + threadIdx.x; i < end; i += 256)
-      dx[base + i] = elem(x[base + i], dy[base + i], dx_add ? dx_add[base + i] : 0.f);
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+      const float o = elem(x[base + i], dy[base + i], dx_add ? dx_add[base + i] : 0.f);
+      amax = fmaxf(amax, fabsf(o));
+      dx[base + i] = o;
+    }
+  }
+  // max |dx| for the f16c8 data-gradient pre-scale (conv_f16c8.hip): float bits order like the floats; the
+  // running maximum is read first, so that after the first few blocks almost none issues an atomic
+  if (amax_bits) {
+    amax = wave_max(amax);
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    if ((threadIdx.x & 63) == 0 && amax < 3.0e38f && bits > *reinterpret_cast<volatile unsigned*>(amax_bits))
+      atomicMax(amax_bits, bits);
   }
 }
 
@@ -284,7 +299,8 @@ int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, flo
 // dx (+= dx_add if given), dgamma, dbeta from the saved stats
 int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
                       const float* stats, const float* dx_add, float* dx, float* dgamma,
-                      float* dbeta, int N, int C, int HW, int G, int silu, void* ws, void* stream) {
+                      float* dbeta, unsigned* dx_amax_bits, int N, int C, int HW, int G, int silu, void* ws,
+                      void* stream) {
   EOVAE_CHECK_ARG(x && dy && gamma && beta && stats && dx && dgamma && dbeta && ws,
                   "gn_silu_bwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "gn_silu_bwd: C=%d G=%d", C, G);
@@ -302,12 +318,16 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, st, sums, gamma,
                      dgamma, dbeta, gm, N, C, cpg, 1.0 / ((double)cpg * HW));
   const int chunks = chunks_for(HW);
+  if (dx_amax_bits && hipMemsetAsync(dx_amax_bits, 0, sizeof(unsigned), st) != hipSuccess) {
+    eovae_set_error("gn_silu_bwd: memset failed");
+    return EOVAE_ERR_LAUNCH;
+  }
   if (silu)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
-                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks);
+                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks, dx_amax_bits);
   else
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
-                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks);
+                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks, dx_amax_bits);
   EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd");
   return EOVAE_OK;
 }

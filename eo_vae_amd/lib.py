@@ -42,7 +42,7 @@ SIGNATURES = {
     'eovae_upsample2x_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'eovae_gn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
-    'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
     'eovae_softmax_bwd_rows': (_i, [_p, _p, _ll, _i, _p]),
@@ -80,7 +80,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 4  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

@@ -116,10 +116,13 @@ int eovae_upsample2x_bwd(const float* du, float* dx, int N, int C, int H, int W,
 size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G);
 int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                       int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream);
-/* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C] */
+/* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C]; dx_amax_bits (nullable, device): receives the
+ * float bits of max|dx| -- the pre-scale input of eovae_conv3x3_f16c8_fwd's data-gradient calls, produced
+ * here for free instead of by a separate eovae_absmax_bits pass over dx */
 int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
                       const float* stats, const float* dx_add, float* dx, float* dgamma,
-                      float* dbeta, int N, int C, int HW, int G, int silu, void* ws, void* stream);
+                      float* dbeta, unsigned* dx_amax_bits, int N, int C, int HW, int G, int silu,
+                      void* ws, void* stream);
 
 /* ----------------------------------------------------------------------------------------
  * Bottleneck attention (csrc/attention.hip): F.scaled_dot_product_attention, one head, d = C

@@ -24,10 +24,12 @@ def test_bench_json_contract():
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
     assert d['unit'] == 'images/sec' and d['higher_is_better'] is True and d['scaling'] == 'weak'
-    assert d['vs_baseline'] is None and d['dtype'] == 'bf16x3' and 'workload' in d['config']
+    from eo_vae_amd import ops
+    assert d['vs_baseline'] is None and d['dtype'] == ops.DEFAULT_PRECISION and 'workload' in d['config']
     assert abs(d['value'] - 16 * 1000.0 / d['ms_per_step']) < 1e-2 * d['value']
     r = d['roofline']
     for k in ['bound', 'achieved', 'peak', 'unit', 'frac', 'traffic']:
         assert k in r, k
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert r['traffic'] is None or r['traffic'] > 0
+    assert 'traffic_source' in r and (r['traffic'] is None or not r['traffic_source'].get('stale'))

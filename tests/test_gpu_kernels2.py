@@ -8,14 +8,14 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['f32', 'bf16x3'], autouse=True)
+@pytest.fixture(params=['f32', 'bf16x3', 'f16c8'], autouse=True)
 def prec(request):
-    """Every test of this file runs on the exact-fp32 MFMA kernels AND on the default split-bf16
-    kernels; the latter carry ~2^-17 per product, so kernel-level tolerances are 10x wider
-    (still 10-100x inside the 1e-3 / 1e-4 parity bars)."""
+    """Every test of this file runs on the exact-fp32 MFMA kernels, on the split-bf16 kernels (~2^-17
+    per product: kernel-level tolerances 10x wider) and on the f16c8 kernels (f16 product + one fp8
+    correction product, ~1e-5 per product: 40x wider) -- all still inside the 1e-3 / 1e-4 parity bars."""
     from eo_vae_amd import ops
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, request.param
-    yield 1.0 if request.param == 'f32' else 10.0
+    yield {'f32': 1.0, 'bf16x3': 10.0, 'f16c8': 40.0}[request.param]
     ops.CONV_PRECISION = old
 
 
@@ -199,7 +199,7 @@ def test_msssim_against_oracle(b, c, s):
     assert vz.item() == 0.0 and float(z.grad.abs().max()) == 0.0
 
 
-def test_fused_adam_trajectory_matches_golden(golden):
+def test_fused_adam_trajectory_matches_golden(golden, prec):
     """3 steps of forward/L1/backward/clip/Adam/LR-schedule on the tiny model (tiny_train fixture)."""
     from oracle import eo_vae_cpu as O
     from eo_vae_amd.autoencoder import EOFluxVAE, get_cosine_schedule_with_warmup
@@ -235,8 +235,9 @@ def test_fused_adam_trajectory_matches_golden(golden):
         assert abs(loss.item() - float(g[f'loss{step}'])) <= 1e-4 * float(g[f'loss{step}'])
         assert abs(float(m.logged['train/grad_norm']) - float(g[f'gnorm{step}'])) <= 2e-3 * float(g[f'gnorm{step}'])
     sd = m.state_dict()
-    assert rel(sd['bn.running_mean'], g['bn_running_mean']) < 1e-4
-    assert rel(sd['bn.running_var'], g['bn_running_var']) < 1e-4
+    stat_bar = 1e-4 * max(1.0, prec / 10.0)   # running latent statistics: 1e-4 (f32, split-bf16), 4e-4 (f16c8)
+    assert rel(sd['bn.running_mean'], g['bn_running_mean']) < stat_bar
+    assert rel(sd['bn.running_var'], g['bn_running_var']) < stat_bar
     assert int(sd['bn.num_batches_tracked']) == int(g['bn_batches'])
     for k in [k for k in g if k.startswith('final.')]:
         got = sd[k[6:]].reshape(-1)[:64].cpu()

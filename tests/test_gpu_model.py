@@ -10,6 +10,19 @@ REL_OUT = 1e-3      # reconstructions / latents
 REL_LOSS = 1e-4     # loss scalars
 
 
+def grad_bar():
+    """Parameter-gradient bar (this repository's own: north_star fixes outputs and loss scalars only).
+    f32 / split-bf16 arithmetic: 5e-4.  f16c8 (2 MFMA units per product, ~1e-5 per product instead of
+    ~4e-6): 1e-3, the north_star's bar for tensors; tools/scheme_probe_grad.py predicts 6.7e-4."""
+    from eo_vae_amd import ops
+    return 1e-3 if ops.CONV_PRECISION == 'f16c8' else 5e-4
+
+
+def stat_bar():
+    from eo_vae_amd import ops
+    return 4e-4 if ops.CONV_PRECISION == 'f16c8' else 1e-4   # running latent statistics
+
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -83,10 +96,10 @@ def test_tiny_train_forward_backward(golden):
             continue
         err = (pp[k].grad.double().cpu() - p.grad.double()).norm().item()
         worst = max(worst, err / max(p.grad.double().norm().item(), 1e-3 * tot))
-    assert worst < 5e-4, worst
+    assert worst < grad_bar(), worst
     sd_o, sd_p = oracle.state_dict(), prod.state_dict()
-    assert rel(sd_p['bn.running_mean'], sd_o['bn.running_mean']) < 1e-4
-    assert rel(sd_p['bn.running_var'], sd_o['bn.running_var']) < 1e-4
+    assert rel(sd_p['bn.running_mean'], sd_o['bn.running_mean']) < stat_bar()
+    assert rel(sd_p['bn.running_var'], sd_o['bn.running_var']) < stat_bar()
     assert int(sd_p['bn.num_batches_tracked']) == int(sd_o['bn.num_batches_tracked'])
 
 
@@ -125,7 +138,8 @@ def test_full_size_kernel_properties():
         assert rel(y12, 0.5 * y1 - 2.0 * y2) < 5e-5                       # linear in x
         eye = torch.zeros(C, C, 3, 3, device='cuda')
         eye[torch.arange(C), torch.arange(C), 1, 1] = 1.0
-        assert rel(ops.conv2d(x1, eye, None, None, 'normal'), x1) < 1e-5    # split-bf16 reproduces fp32 data
+        # hi + lo reproduces fp32 data: to 2^-17 with split-bf16, to 2^-12 * 2^-3 (the e5m2 residual) with f16c8
+        assert rel(ops.conv2d(x1, eye, None, None, 'normal'), x1) < (5e-5 if ops.CONV_PRECISION == 'f16c8' else 1e-5)
     xa = x1.clone().requires_grad_(True)
     ya = ops.conv2d(xa, w, b, None, 'normal')
     gy = torch.randn_like(ya)
