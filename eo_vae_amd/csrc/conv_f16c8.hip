@@ -642,6 +642,452 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// weight gradient with f16c8 operands:  dWp[tap][co][ci] += sum_{n,pix} dY[n][co][pix] * Xv[n][ci][pix @ tap]
+// Same tiling, staging pipeline and sub-pixel / space-to-depth forms as wgrad3x3_bf16_kernel (conv_bf16x3.hip:
+// block = 128 co x 64 ci x 9 taps, K = pixels in tiles of 2 rows x 32, both operands staged
+// channel-contiguous and gathered by transposing LDS reads); what differs is the arithmetic.  Per output row of
+// 32 pixels and tap: 2 x v_mfma_f32_32x32x16_f16 (dy_hi * x_hi) + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 whose
+// K = 64 is [dy_lo' | dy_hi'] . [x_hi' | x_lo'] (all e5m2; the lo' images carry 2^12, undone by the A block
+// scale) = 4 MFMA units where split-bf16 needs 6.  dy is pre-scaled by the power of two derived from its
+// amax (same value the data-gradient call uses) and the accumulators are un-scaled on the way out.
+// ---------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x8 tr_frag16(const unsigned char* p0, const unsigned char* p1) {
+  using lds4 = __attribute__((address_space(3))) s16x4;
+  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p0));
+  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p1));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ int wg_src_index(int mode, int oy0, int ox0, int r, int c, int Hin, int Win) {
+  const int vy = oy0 + r - 1, vx = ox0 + c - 1;
+  if (mode == MODE_NORMAL)
+    return ((unsigned)vy < (unsigned)Hin && (unsigned)vx < (unsigned)Win) ? vy * Win + vx : -1;
+  return ((unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win)) ? (vy >> 1) * Win + (vx >> 1) : -1;
+}
+
+#ifndef EOVAE_WGRAD_BLOCKS
+#define EOVAE_WGRAD_BLOCKS 256
+#endif
+
+struct WgCArgs {
+  const float* x;
+  const float* dy;
+  float* db;   // [Cout] bias gradient (sum of dy over n, pixels), pre-zeroed, or null
+  float* dwp;  // [9][Cout][Cin] fp32, pre-zeroed
+  const unsigned* dyamax;   // float bits of max|dy| (device) or null
+  int N, Cin, Hin, Win, Cout, Hout, Wout;
+  int mode;
+  int tiles_x, tiles_y, ntiles, ncib;
+  int subpix, creal, cpb;   // as WgBArgs (conv_bf16x3.hip)
+};
+
+template <int SUBPIX>
+__global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
+  constexpr int NT = SUBPIX ? 4 : 9;  // accumulated taps: all 9, or the parity's 2x2 support
+  constexpr int PW = 32, XW = 40, XWV = 34, NXP = 4 * XW;  // 2 output rows + halo; LDS row pitch 40
+                                                          // pixels (34 valid) keeps every window start = kx (mod 8)
+  constexpr int DPART = 4 * 64 * 64;                      // f16 [4 co-tiles][64 pix][32 co]
+  constexpr int D8IMG = 4 * 64 * 32, D8 = 2 * D8IMG;      // e5m2 [dyl' | dyh'][4 co-tiles][64 pix][32 co]
+  constexpr int XPART = 2 * NXP * 64;                     // f16 [2 ci-tiles][160 pix][32 ci]
+  constexpr int X8IMG = 2 * NXP * 32, X8 = 2 * X8IMG;     // e5m2 [xh' | xl'][2 ci-tiles][160 pix][32 ci]
+  constexpr int OFF_D8 = DPART, OFF_X = DPART + D8, OFF_X8 = OFF_X + XPART;
+  constexpr int BUF = OFF_X8 + X8;                        // 72 KiB, two of them
+  constexpr int XQ = NXP * 8 / 4;                         // X tasks per k-step (272)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  const int ct = wave & 3, cih = wave >> 2;
+  const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
+  const int par = SUBPIX == 1 ? cob / a.cpb : (SUBPIX == 2 ? (cib * 64) / a.creal : 0);
+  const int py = par >> 1, px = par & 1;
+  const int dych = SUBPIX == 1 ? a.creal : a.Cout;   // channels / plane of the stored dy tensor
+  const size_t in_plane = (size_t)a.Hin * a.Win;
+  const size_t out_plane = SUBPIX == 1 ? (size_t)a.Hout * a.Wout * 4 : (size_t)a.Hout * a.Wout;
+  // per-lane byte offsets inside a swizzled [pixel][32 ch] image for the two transposed 4x16 block
+  // reads of a fragment (pixel rows lpart and lpart+4 of the 16-pixel k-step, 8-byte chunk lchunk)
+  const int lpart = 8 * (g >> 1) + lq, lchunk = 4 * (g & 1) + lp;
+  // dY image: chunk ^ ((row>>1)&7); row = 16*ks + lpart(+4) and 16*ks never reaches those bits
+  const int sa0 = lpart * 64 + ((lchunk ^ ((lpart >> 1) & 7)) * 8);
+  const int sa1 = (lpart + 4) * 64 + ((lchunk ^ (((lpart + 4) >> 1) & 7)) * 8);
+  // X image: 16-byte unit ^ ((pix>>1)&3); pix = base + lpart(+4), so one offset per (base & 7)
+  auto sx_of = [&](int res) {
+    return lpart * 64 + (((lchunk >> 1) ^ (((res + lpart) >> 1) & 3)) * 16) + (lchunk & 1) * 8;
+  };
+  // window start = kx (mod 8): named scalars, never an indexable array (that would go to scratch)
+  const int sx0 = sx_of(0), sx1 = sx_of(1), sx2 = sx_of(2), sx4 = sx_of(4), sx5 = sx_of(5), sx6 = sx_of(6);
+  // fp8 fragments by ds_read_b64_tr_b8 from [pixel][32 channel bytes] images.  In a 16-lane group lane 2j+p
+  // points at 8 bytes; destination lane 8p+c receives byte c of the eight p-rows (tools/probe_tr8.hip).  So
+  // source lane (j, p) of group G points at pixel P+j, channel octet 2(G&1)+p of image G>>1 (= the MFMA
+  // K-block h of the destination lanes), and destination lane (h, r) gets channel r at pixels P..P+7.
+  const int l8 = (li >> 1) * 32 + ((g & 1) * 2 + (li & 1)) * 8;
+  const int a8off = OFF_D8 + (g >> 1) * D8IMG + ct * (64 * 32) + l8;      // dyl' (h = 0) | dyh' (h = 1)
+  const int b8off = OFF_X8 + (g >> 1) * X8IMG + cih * (NXP * 32) + l8;    // xh'  (h = 0) | xl'  (h = 1)
+  // dy pre-scale: the power of two that puts its amax at 2^13..2^14 (gradients sit far below f16's range)
+  float dys = 1.f, dyinv = 1.f;
+  if (a.dyamax) {
+    const unsigned bits = *a.dyamax;
+    if (bits) {
+      const int e = expo_of_bits(bits);
+      dys = pow2f(13 - e);
+      dyinv = pow2f(e - 13);
+    }
+  }
+  const int sc_a = 127 - 12, sc_b = 127;   // E8M0: both K blocks carry one operand scaled by 2^12
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  // staging registers: HALF a tile (one output row of 32 pixels + its share of the halo) is issued
+  // before two k-steps (54 MFMAs per wave, ~1.7 us per SIMD pair) and committed to the other LDS
+  // buffer after them.  Timing-only builds (EOVAE_WABL) show staging and MFMA time adding up
+  // (0.26-0.35 ms + 0.6-0.7 ms = 1.0-1.2 ms); doubling the prefetch distance from one k-step to two
+  // measured +0..3 % on the same box, so load LATENCY is not what serialises them.
+  // dY: 2 tasks (4 channels x 1 pixel) per thread; X halo: 640 tasks (8 channels x 1 pixel).
+  constexpr int XHALF = NXP * 8 / 2;   // 640
+  float dyr[2][4], xr[2][8];
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};  // bias-gradient partials of this thread's 4 channels
+  const bool do_db = a.db != nullptr && cib == 0 && SUBPIX != 1;
+  unsigned vmask = 0xf;  // bit i: dY task i valid; bit 2+i: X task i valid (set by issue*, used by commit)
+  auto issue = [&](int tile, int hf) __attribute__((always_inline)) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty * 2, ox0 = tx * PW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels, x-half i
+      const int oy = oy0 + hf, ox = ox0 + 16 * i + pixl;
+      const bool ok = oy < a.Hout && ox < a.Wout;
+      const size_t pixoff = SUBPIX == 1 ? (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px
+                                        : (size_t)oy * a.Wout + ox;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = cob * 128 + quad * 4 + j;
+        dyr[i][j] = (ok && co < a.Cout)
+                        ? a.dy[((size_t)n * dych + (co - (SUBPIX == 1 ? par * a.creal : 0))) * out_plane + pixoff]
+                        : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tt = tid + i * 512;
+      if (tt < XHALF) {
+        const int t2 = hf * XHALF + tt;
+        const int oct = t2 / NXP, pix = t2 - oct * NXP;
+        const int rr = pix / XW, cc = pix - rr * XW;
+        int si = -1;
+        if (cc < XWV) {
+          if (SUBPIX == 2) {  // space-to-depth gather: low-res halo pixel (vy,vx) -> x[2vy+py][2vx+px]
+            const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
+            if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
+              si = (2 * vy + py) * a.Win + 2 * vx + px;
+          } else {
+            si = wg_src_index(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+          }
+        }
+        const int xch = SUBPIX == 2 ? a.creal : a.Cin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = cib * 64 + oct * 8 + j;
+          xr[i][j] = (si >= 0 && ci < a.Cin)
+                         ? a.x[((size_t)n * xch + (ci - (SUBPIX == 2 ? par * a.creal : 0))) * in_plane + si]
+                         : 0.f;
+        }
+      }
+    }
+    vmask = 0xf;  // zeros already selected
+  };
+  // Fast path (every channel of the block's 128 co x 64 ci slab exists -- all layers of the model):
+  // UNCONDITIONAL loads from clamped addresses, validity kept as 4 mask bits and applied when the
+  // registers are converted.  Predicated loads (`ok ? p[i] : 0`) compile to an exec-mask branch per
+  // load plus vmcnt(0) drains between them, i.e. several fully exposed memory latencies per half tile.
+  const bool fullc = cob * 128 + 128 <= a.Cout && cib * 64 + 64 <= a.Cin;
+  const float* dyb = a.dy + (size_t)(cob * 128 - (SUBPIX == 1 ? par * a.creal : 0)) * out_plane;
+  const float* xb = a.x + (size_t)(cib * 64 - (SUBPIX == 2 ? par * a.creal : 0)) * in_plane;
+  auto issue_fast = [&](int tile, int hf) __attribute__((always_inline)) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty * 2, ox0 = tx * PW;
+    const int xch = SUBPIX == 2 ? a.creal : a.Cin;
+    const float* dyn = dyb + (size_t)n * dych * out_plane;   // wave-uniform bases
+    const float* xn = xb + (size_t)n * xch * in_plane;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pixl = tid & 15, quad = tid >> 4;
+      const int oy = oy0 + hf, ox = ox0 + 16 * i + pixl;
+      const bool ok = oy < a.Hout && ox < a.Wout;
+      const unsigned pixoff = !ok ? 0u
+                              : (SUBPIX == 1 ? (unsigned)((2 * oy + py) * (2 * a.Wout) + 2 * ox + px)
+                                             : (unsigned)(oy * a.Wout + ox));
+      m |= (ok ? 1u : 0u) << i;
+      const float* src = dyn + (size_t)(quad * 4) * out_plane + pixoff;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dyr[i][j] = src[(size_t)j * out_plane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tt = tid + i * 512;
+      const int t2 = hf * XHALF + (tt < XHALF ? tt : 0);
+      const int oct = t2 / NXP, pix = t2 - oct * NXP;
+      const int rr = pix / XW, cc = pix - rr * XW;
+      int si = -1;
+      if (cc < XWV && tt < XHALF) {
+        if (SUBPIX == 2) {
+          const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
+          if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
+            si = (2 * vy + py) * a.Win + 2 * vx + px;
+        } else {
+          si = wg_src_index(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
+        }
+      }
+      m |= (si >= 0 ? 1u : 0u) << (2 + i);
+      const float* src = xn + (size_t)(oct * 8) * in_plane + (si >= 0 ? si : 0);
+      if (i == 0 || tid < XHALF - 512) {   // second round: 128 of the 512 threads
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = src[(size_t)j * in_plane];
+      }
+    }
+    vmask = m;
+  };
+  auto commit = [&](int buf, int hf) __attribute__((always_inline)) {
+    unsigned char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!((vmask >> i) & 1)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dyr[i][j] = 0.f;
+      }
+      if (!((vmask >> (2 + i)) & 1)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pixl = tid & 15, quad = tid >> 4;
+      typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      f16x4v hi;
+      float v[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = dyr[i][j] * dys;
+        hi[j] = (_Float16)v[j];
+        lo[j] = v[j] - (float)hi[j];
+      }
+      s16x2 l8v = {0, 0};
+      l8v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l8v, lo[0], lo[1], 0x1p-12f, false);
+      l8v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l8v, lo[2], lo[3], 0x1p-12f, true);
+      int h8v = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+      h8v = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h8v, true);
+      const int ks = 2 * hf + i;
+      const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
+      *reinterpret_cast<f16x4v*>(base + off) = hi;
+      const int off8 = OFF_D8 + (quad >> 3) * (64 * 32) + (ks * 16 + pixl) * 32 + (quad & 7) * 4;
+      *reinterpret_cast<int*>(base + off8) = __builtin_bit_cast(int, l8v);   // image 0: dyl'
+      *reinterpret_cast<int*>(base + off8 + D8IMG) = h8v;                    // image 1: dyh'
+      if (do_db) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dbs[j] += dyr[i][j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tt = tid + i * 512;
+      if (tt < XHALF) {
+        const int t2 = hf * XHALF + tt;
+        const int oct = t2 / NXP, pix = t2 - oct * NXP;
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        f16x8 hi;
+        float lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          hi[j] = (_Float16)xr[i][j];
+          lo[j] = xr[i][j] - (float)hi[j];
+        }
+        s16x2 l0 = {0, 0}, l1 = {0, 0};
+        l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+        l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+        l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+        l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+        int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][0], xr[i][1], 0, false);
+        h0 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][2], xr[i][3], h0, true);
+        int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][4], xr[i][5], 0, false);
+        h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][6], xr[i][7], h1, true);
+        const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
+        *reinterpret_cast<f16x8*>(base + off) = hi;
+        const int off8 = OFF_X8 + (oct >> 2) * (NXP * 32) + pix * 32 + (oct & 3) * 8;
+        i32x2 hv, lv;
+        hv[0] = h0; hv[1] = h1;
+        lv[0] = __builtin_bit_cast(int, l0); lv[1] = __builtin_bit_cast(int, l1);
+        *reinterpret_cast<i32x2*>(base + off8) = hv;            // image 0: xh'
+        *reinterpret_cast<i32x2*>(base + off8 + X8IMG) = lv;    // image 1: xl'
+      }
+    }
+  };
+  // PARC = compile-time parity (sub-pixel form) so every tap index / swizzle offset is static
+  auto tap_ok_of = [](int t, int PY, int PX) { return !(SUBPIX == 2 && (((t >> 1) && PY) || ((t & 1) && PX))); };
+  auto tap_yx = [](int t, int PY, int PX, int& ky, int& kx) {
+    ky = SUBPIX == 1 ? PY + (t >> 1) : (SUBPIX == 2 ? 1 + (t >> 1) : t / 3);
+    kx = SUBPIX == 1 ? PX + (t & 1) : (SUBPIX == 2 ? 1 + (t & 1) : t % 3);
+  };
+  // f16 main term of one 16-pixel k-step: one A fragment, one B fragment per tap
+  auto compute16_p = [&](const unsigned char* base, int ks, auto parc) __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+    const int row = ks >> 1, x0 = 16 * (ks & 1);
+    const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
+    const f16x8 ah = __builtin_bit_cast(f16x8, tr_frag16(ap + sa0, ap + sa1));
+    auto xfrag = [&](int t) __attribute__((always_inline)) {
+      int ky, kx;
+      tap_yx(t, PY, PX, ky, kx);
+      // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8)
+      const unsigned char* bp = base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64;
+      const int o0 = kx == 0 ? sx0 : (kx == 1 ? sx1 : sx2);
+      const int o1 = (kx == 0 ? sx4 : (kx == 1 ? sx5 : sx6)) + 4 * 64;
+      return __builtin_bit_cast(f16x8, tr_frag16(bp + o0, bp + o1));
+    };
+    f16x8 bh = xfrag(0), nh;   // tap 0 is active for every parity
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!tap_ok_of(t, PY, PX)) continue;
+      int tn = t + 1;
+      while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
+      if (tn < NT) nh = xfrag(tn);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+      bh = nh;
+    }
+  };
+  // both correction terms of one 32-pixel output row: K = 64 = [dyl' | dyh'] . [xh' | xl']
+  auto compute8_p = [&](const unsigned char* base, int row, auto parc) __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+    auto frag8 = [&](const unsigned char* p) __attribute__((always_inline)) {
+      using lds2 = __attribute__((address_space(3))) i32x2;
+      const i32x2 v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p));
+      const i32x2 v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 256));
+      const i32x2 v2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 512));
+      const i32x2 v3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 768));
+      const i32x4 lo = __builtin_shufflevector(v0, v1, 0, 1, 2, 3), hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3);
+      return (i32x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const i32x8 a8 = frag8(base + a8off + row * (32 * 32));
+    auto xfrag8 = [&](int t) __attribute__((always_inline)) {
+      int ky, kx;
+      tap_yx(t, PY, PX, ky, kx);
+      return frag8(base + b8off + ((row + ky) * XW + kx) * 32);
+    };
+    // no register double buffering (144 accumulators + 24 staging registers leave room for ONE 8-VGPR B
+    // fragment; the SIMD's partner wave covers the read latency) and a scheduling fence per tap: left alone
+    // the compiler hoists the transposed reads of all nine taps above the first MFMA and spills them
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!tap_ok_of(t, PY, PX)) continue;
+      const i32x8 b8 = xfrag8(t);
+      acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 1 /* A: e5m2 */, 1 /* B: e5m2 */, 0,
+                                                                 sc_a, 0, sc_b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto compute = [&](const unsigned char* base, int ks) __attribute__((always_inline)) {
+    if (!SUBPIX) { compute16_p(base, ks, std::integral_constant<int, 0>{}); return; }
+    switch (par) {  // uniform
+      case 0: compute16_p(base, ks, std::integral_constant<int, 0>{}); break;
+      case 1: compute16_p(base, ks, std::integral_constant<int, 1>{}); break;
+      case 2: compute16_p(base, ks, std::integral_constant<int, 2>{}); break;
+      default: compute16_p(base, ks, std::integral_constant<int, 3>{}); break;
+    }
+  };
+  auto compute8 = [&](const unsigned char* base, int row) __attribute__((always_inline)) {
+    if (!SUBPIX) { compute8_p(base, row, std::integral_constant<int, 0>{}); return; }
+    switch (par) {  // uniform
+      case 0: compute8_p(base, row, std::integral_constant<int, 0>{}); break;
+      case 1: compute8_p(base, row, std::integral_constant<int, 1>{}); break;
+      case 2: compute8_p(base, row, std::integral_constant<int, 2>{}); break;
+      default: compute8_p(base, row, std::integral_constant<int, 3>{}); break;
+    }
+  };
+
+  // The tile loop is instantiated once per load path: a run-time choice between issue_fast() and
+  // issue() inside ONE loop makes the loaded registers phi nodes, and the compiler then waits for
+  // vmcnt(0) and copies them at the join -- right after issuing the loads, before the MFMAs.
+  auto run = [&](auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_t)::value;
+    auto load = [&](int tile, int hf) __attribute__((always_inline)) {
+      if constexpr (FULL) issue_fast(tile, hf); else issue(tile, hf);
+    };
+    int tile = blockIdx.y;
+    if (tile < a.ntiles) {
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        load(tile, hf);
+        commit(0, hf);
+      }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < a.ntiles; tile += gridDim.y) {
+      const int next = tile + gridDim.y;
+      const bool has_next = next < a.ntiles;
+      const unsigned char* base = smem + cur * BUF;
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        if (has_next) load(next, hf);
+#pragma unroll 1
+        for (int sub = 0; sub < 2; ++sub) compute(base, 2 * hf + sub);
+        // The staged half tile is committed BEFORE the row's fp8 products: its 24 staging registers and the
+        // 16 fragment registers of the scaled MFMAs do not fit beside 144 accumulators at the same time
+        // (230 spilled VGPRs otherwise).  Scheduling fences keep the compiler from undoing the order.
+        if (has_next) commit(cur ^ 1, hf);
+        __builtin_amdgcn_sched_barrier(0);
+        compute8(base, hf);   // the row's two k-steps share one K = 64 correction product per tap
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  };
+  if (fullc) run(std::true_type{}); else run(std::false_type{});
+
+  if (do_db) {  // lanes 16q..16q+15 hold the same 4 channels at 16 different pixels
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = dbs[j];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      const int co = cob * 128 + (tid >> 4) * 4 + j;
+      if ((tid & 15) == 0 && co < a.Cout) atomicAdd(&a.db[co], v);
+    }
+  }
+  const int ci = cib * 64 + cih * 32 + r;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int tap = SUBPIX == 1 ? (py + (t >> 1)) * 3 + px + (t & 1)
+                                  : (SUBPIX == 2 ? (1 + (t >> 1)) * 3 + 1 + (t & 1) : t);
+      if (SUBPIX == 2 && (((t >> 1) && py) || ((t & 1) && px))) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = cob * 128 + ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (co < a.Cout) atomicAdd(&a.dwp[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[t][q] * dyinv);
+      }
+    }
+  }
+}
+
+
 // max |x| as float bits (a non-negative float orders like its bit pattern), atomically into *out
 __global__ void absmax_bits_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
   float m = 0.f;
@@ -846,6 +1292,46 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   EOVAE_LAUNCH_C8(8)
 #undef EOVAE_LAUNCH_C8
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_fwd");
+  return EOVAE_OK;
+}
+
+// dwp[9][Cout][Cin] += dY (x) Xv with f16c8 operands; arguments as eovae_conv3x3_bf16_wgrad plus dyamax
+// (device pointer to the float bits of max|dy|, eovae_absmax_bits / eovae_gn_silu_bwd; NULL = unscaled dy)
+int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db, const unsigned* dyamax, int N,
+                              int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
+                              void* stream) {
+  EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_f16c8_wgrad: null pointer");
+  EOVAE_CHECK_ARG(!(db && subpix == 1), "conv3x3_f16c8_wgrad: db is not produced in subpix 1");
+  EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_f16c8_wgrad: subpix %d", subpix);
+  EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_f16c8_wgrad: mode %d unsupported", mode);
+  WgCArgs a;
+  a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax;
+  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
+  a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
+  if (subpix == 1) {
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && Cout % 128 == 0 && Hout == 2 * Hin && Wout == 2 * Win,
+                    "conv3x3_f16c8_wgrad: subpix 1 needs mode 0, Cout %% 128 == 0 and a 2x dy");
+    a.creal = Cout; a.cpb = Cout / 128; a.Cout = 4 * Cout; a.Hout = Hin; a.Wout = Win;
+    Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
+  } else if (subpix == 2) {
+    EOVAE_CHECK_ARG(mode == MODE_NORMAL && Cin % 64 == 0 && Hin == 2 * Hout && Win == 2 * Wout,
+                    "conv3x3_f16c8_wgrad: subpix 2 needs mode 0, Cin %% 64 == 0 and a 1/2 dy");
+    a.creal = Cin; a.Cin = 4 * Cin;
+    Cin = a.Cin;
+  }
+  a.tiles_x = cdiv(Wout, 32); a.tiles_y = cdiv(Hout, 2);
+  a.ntiles = N * a.tiles_x * a.tiles_y;
+  a.ncib = cdiv(Cin, 64);
+  const int ncob = cdiv(Cout, 128);
+  int split = EOVAE_WGRAD_BLOCKS / (a.ncib * ncob);   // one block per CU (conv_bf16x3.hip)
+  if (split < 1) split = 1;
+  if (split > a.ntiles) split = a.ntiles;
+  dim3 grid(a.ncib * ncob, split);
+  hipStream_t st = (hipStream_t)stream;
+  if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1>), grid, dim3(512), 0, st, a);
+  else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0>), grid, dim3(512), 0, st, a);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad");
   return EOVAE_OK;
 }
 

@@ -199,6 +199,19 @@ def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode
                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
 
 
+def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix):
+    """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16."""
+    lib = L.load()
+    if CONV_PRECISION == 'f16c8':
+        L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax_of(dy)), n,
+                                              cin, h, w, cout, ho, wo, mode, subpix, L.stream()),
+                'eovae_conv3x3_f16c8_wgrad')
+    else:
+        L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w, cout, ho,
+                                             wo, mode, _PREC[CONV_PRECISION], subpix, L.stream()),
+                'eovae_conv3x3_bf16_wgrad')
+
+
 def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None):
     """3x3 stride-1 conv / data-gradient on the 16-bit matrix cores (weight in PyTorch layout).
     amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode."""
@@ -282,9 +295,7 @@ def down_conv_s2d_wgrad(x, dy, weight, db=None):
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * cout * 4 * cin, dtype=torch.float32, device=x.device)
-    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w, cout, h // 2,
-                                         w // 2, MODE_NORMAL, _PREC[CONV_PRECISION], 2, L.stream()),
-            'eovae_conv3x3_bf16_wgrad')
+    _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 2)
     dw = torch.empty_like(weight)
     L.check(lib.eovae_down_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_down_fold')
     return dw
@@ -330,9 +341,7 @@ def up_conv_subpix_wgrad(x, dy, weight):
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * 4 * cout * cin, dtype=torch.float32, device=x.device)
-    L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), None, n, cin, h, w, cout, 2 * h, 2 * w,
-                                         MODE_NORMAL, _PREC[CONV_PRECISION], 1, L.stream()),
-            'eovae_conv3x3_bf16_wgrad')
+    _launch_wgrad3x3(x, dy, dwp, None, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1)
     dw = torch.empty_like(weight)
     L.check(lib.eovae_subpix_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_subpix_fold')
     return dw
@@ -468,9 +477,7 @@ class Conv2dFn(torch.autograd.Function):
             if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
                 if want_db:  # bias gradient rides on the dy tiles the wgrad kernel stages anyway
                     db = torch.zeros(cout, dtype=torch.float32, device=x.device)
-                L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w,
-                                                     cout, dy.shape[2], dy.shape[3], m, _PREC[CONV_PRECISION],
-                                                     0, L.stream()), 'eovae_conv3x3_bf16_wgrad')
+                _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, dy.shape[2], dy.shape[3], m, 0)
             else:
                 L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
                                                dy.shape[2], dy.shape[3], ks, m, L.stream()),

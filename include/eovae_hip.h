@@ -81,6 +81,12 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, void* stream);
+/* f16c8 weight gradient (same tiling and sub-pixel forms as eovae_conv3x3_bf16_wgrad; replaces the same
+ * autograd call site of F.conv2d, layers.py:29-50, 70-110): per 32 pixels and tap 2 f16 MFMAs + 1 block-scaled
+ * fp8 MFMA [dy_lo|dy_hi].[x_hi|x_lo].  dyamax as for the data gradient (NULL = dy used unscaled). */
+int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db,
+                              const unsigned* dyamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
+                              int Wout, int mode, int subpix, void* stream);
 /* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);

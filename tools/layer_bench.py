@@ -29,7 +29,10 @@ for cin, cout, hw in shapes:
         if prec == 'f16c8':
             wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
             L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
-            fns[prec] = (lambda wp=wp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, L.stream()), None)
+            dwp8 = torch.zeros(9 * cout * cin, device='cuda')
+            amax = ops.absmax_bits(dy)
+            fns[prec] = (lambda wp=wp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, L.stream()),
+                         lambda dwp8=dwp8, amax=amax: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp8), None, L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, L.stream()))
         else:
             p = ops._PREC[prec]
             wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(cout, cin, 0), dtype=torch.bfloat16, device='cuda')
