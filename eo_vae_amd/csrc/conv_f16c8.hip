@@ -239,16 +239,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) xr[i][j] = *reinterpret_cast<const float*>(cj + xoff[i]);
   };
-  // convert one task's 8 channels and write its three LDS payloads (f16 x 8, lo' x 8, hi' x 8) to buffer xb
+  // LDS byte offsets of this thread's tasks inside a halo buffer (f16 row, fp8 lo' row; ~0u = no task):
+  // lane-only quantities, computed once
+  unsigned xst16[XPT], xst8[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int tk = tid + i * NTHR;
+    const int g = tk / NPX, pix = tk - g * NPX;
+    xst16[i] = tk < XTASKS ? (unsigned)(g * (NPX * 16) + pix * 16) : ~0u;
+    xst8[i] = (unsigned)(XF16 + ((g >> 1) * NPX + pix) * 16 + (g & 1) * 8);
+  }
+  // convert one task's 8 channels and write its three LDS payloads (f16 x 8, lo' x 8, hi' x 8) to buffer xb.
+  // 3.5 VALU instructions per element: v_mul (scale and validity), v_cvt_pk_f16_f32, v_fma_mix_f32 (the residual
+  // straight from the packed f16: hipcc's own code converts back to f32 and subtracts, 5.5 per element),
+  // v_cvt_scalef32_pk_bf8_f32 (lo' = e5m2(lo * 2^12): the instruction divides by its scale), v_cvt_pk_bf8_f32.
   auto convert_store_x = [&](int xb) __attribute__((always_inline)) {
     unsigned char* xsm = smem + xb * XSET;
-    int xt = tid;
-    asm volatile("" : "+v"(xt));
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int tk = xt + i * NTHR;
       const float sm = ((xokm >> i) & 1) ? xs : 0.f;   // validity folded into the scale
-      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
       typedef short s16x2 __attribute__((ext_vector_type(2)));
       float v[8], lo[8];
       int pk[4];
@@ -256,14 +265,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       for (int j = 0; j < 8; j += 2) {
         v[j] = xr[i][j] * sm;
         v[j + 1] = xr[i][j + 1] * sm;
-        f16x2 hh;
-        hh[0] = (_Float16)v[j];
-        hh[1] = (_Float16)v[j + 1];
-        pk[j >> 1] = __builtin_bit_cast(int, hh);
-        lo[j] = v[j] - (float)hh[0];
-        lo[j + 1] = v[j + 1] - (float)hh[1];
+        int hh;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v[j]), "v"(v[j + 1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hh), "v"(v[j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hh), "v"(v[j + 1]));
+        pk[j >> 1] = hh;
       }
-      // lo' = e5m2(lo * 2^12): the conversion instruction divides by its scale operand
       s16x2 l0 = {0, 0}, l1 = {0, 0};
       l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
       l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
@@ -273,17 +280,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
       int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
       h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h1, true);
-      if (tk < XTASKS) {
-        const int g = tk / NPX, pix = tk - g * NPX;
+      if (xst16[i] != ~0u) {
         i32x4 hv;
         hv[0] = pk[0]; hv[1] = pk[1]; hv[2] = pk[2]; hv[3] = pk[3];
         i32x2 lv, uv;
         lv[0] = __builtin_bit_cast(int, l0); lv[1] = __builtin_bit_cast(int, l1);
         uv[0] = h0; uv[1] = h1;
-        *reinterpret_cast<i32x4*>(xsm + g * (NPX * 16) + pix * 16) = hv;
-        unsigned char* p8 = xsm + XF16 + ((g >> 1) * NPX + pix) * 16 + (g & 1) * 8;
-        *reinterpret_cast<i32x2*>(p8) = lv;                      // part 0: lo'
-        *reinterpret_cast<i32x2*>(p8 + 2 * NPX * 16) = uv;       // part 1: hi'
+        *reinterpret_cast<i32x4*>(xsm + xst16[i]) = hv;
+        *reinterpret_cast<i32x2*>(xsm + xst8[i]) = lv;                     // part 0: lo'
+        *reinterpret_cast<i32x2*>(xsm + xst8[i] + 2 * NPX * 16) = uv;      // part 1: hi'
       }
     }
   };
@@ -379,62 +384,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   const unsigned wl16 = (unsigned)(OFF_W + h * (BM * 16) + (wco + r) * 16);            // f16 weight image
   const unsigned wl8 = (unsigned)(OFF_W + WF16 + (h * 2) * (BM * 16) + (wco + r) * 16); // fp8 weight images
 
-  // one tap: 2 co-tiles x NI pixel-row tiles x (2 f16 MFMAs + 1 scaled fp8 MFMA).  wslot = byte offset of
-  // the tap's ring slot; (ky, kx) are compile-time constants on the plain path.
-  auto compute_tap = [&](unsigned wslot, unsigned xsel, int ky, int kx) __attribute__((always_inline)) {
+  // One tap = 2 co-tiles x NI pixel-row tiles x (2 f16 MFMAs + 1 scaled fp8 MFMA), in two passes with their
+  // own fragment sets.  A stage issues the reads of the NEXT pass before the MFMAs of the current one (scheduling
+  // fences keep that order): left to the compiler each pass began with its 8 ds_read_b128 and an
+  // `s_waitcnt lgkmcnt(0)`, four fully exposed LDS latencies per stage with both waves of a SIMD in step.
+  struct Frag16 { f16x8 a[2][2]; f16x8 b[NI][2]; };
+  struct Frag8 { i32x8 a[2]; i32x8 b[NI]; };
+  auto load16 = [&](Frag16& f, unsigned wslot, unsigned xsel, int ky, int kx) __attribute__((always_inline)) {
     const unsigned tapoff = (unsigned)((ky * XW + kx) * 16) + xsel;
-    {  // pass 1: f16 main term.  Fragment of k-step s = octet 2s + h.
-      f16x8 ah[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        f.a[i][s] = *reinterpret_cast<const f16x8*>(smem + (wl16 + wslot) + (2 * s) * (BM * 16) + i * 512);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        f.b[j][s] = *reinterpret_cast<const f16x8*>(smem + (xl16 + tapoff) + (2 * s) * (NPX * 16) + j * (XW * 16));
+  };
+  auto load8 = [&](Frag8& f, unsigned wslot, unsigned xsel, int ky, int kx) __attribute__((always_inline)) {
+    const unsigned tapoff = (unsigned)((ky * XW + kx) * 16) + xsel;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned char* p = smem + (wl8 + wslot) + i * 512;
+      const i32x4 q0 = *reinterpret_cast<const i32x4*>(p);
+      const i32x4 q1 = *reinterpret_cast<const i32x4*>(p + BM * 16);
+      f.a[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const unsigned char* p = smem + (xl8 + tapoff) + j * (XW * 16);
+      const i32x4 q0 = *reinterpret_cast<const i32x4*>(p);
+      const i32x4 q1 = *reinterpret_cast<const i32x4*>(p + NPX * 16);
+      f.b[j] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto mma16 = [&](const Frag16& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-          ah[i][s] = *reinterpret_cast<const f16x8*>(smem + (wl16 + wslot) + (2 * s) * (BM * 16) + i * 512);
-      auto xfrag = [&](int j, f16x8 (&f)[2]) __attribute__((always_inline)) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+  };
+  auto mma8 = [&](const Frag8& f) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-          f[s] = *reinterpret_cast<const f16x8*>(smem + (xl16 + tapoff) + (2 * s) * (NPX * 16) + j * (XW * 16));
-      };
-      f16x8 bh[2], nh[2];
-      xfrag(0, bh);
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        if (j + 1 < NI) xfrag(j + 1, nh);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][s], bh[s], acc[i][j], 0, 0, 0);
-        bh[0] = nh[0];
-        bh[1] = nh[1];
-      }
-    }
-    {  // pass 2: both correction terms in one K = 64 block-scaled product
-      i32x8 a8[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned char* p = smem + (wl8 + wslot) + i * 512;
-        const i32x4 q0 = *reinterpret_cast<const i32x4*>(p);
-        const i32x4 q1 = *reinterpret_cast<const i32x4*>(p + BM * 16);
-        a8[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-      auto xfrag8 = [&](int j) __attribute__((always_inline)) {
-        const unsigned char* p = smem + (xl8 + tapoff) + j * (XW * 16);
-        const i32x4 q0 = *reinterpret_cast<const i32x4*>(p);
-        const i32x4 q1 = *reinterpret_cast<const i32x4*>(p + NPX * 16);
-        return (i32x8)__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
-      };
-      i32x8 b8 = xfrag8(0), n8;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        if (j + 1 < NI) n8 = xfrag8(j + 1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8, acc[i][j], 0 /* A: e4m3 */,
-                                                                      1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
-        b8 = n8;
-      }
-    }
+      for (int i = 0; i < 2; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.a[i], f.b[j], acc[i][j], 0 /* A: e4m3 */,
+                                                                    1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
   };
 
   // Epilogue of one tile: as conv_bf16x3.hip (batched unconditional bias / residual loads, plain stores on
@@ -581,26 +582,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
         }
         C8_STAMP(1);
         const unsigned wslot = (unsigned)((q & 1) * 2 * WTAP);
+        {
+          const unsigned xsel = XDB ? (unsigned)(xbuf * XSET) : 0u;
+          const bool two = 2 * s + 1 < nt;   // uniform
+          int ky0, kx0, ky1, kx1;
+          tap_of(cur, chunk, 2 * s, ky0, kx0);
+          tap_of(cur, chunk, 2 * s + 1, ky1, kx1);
+          // halo groups of the staged chunk: two behind each of the taps 0..3 (plain path); all of them in
+          // stage 0 when the conversion is in stage 1
+          auto stage_loads = [&](int tt) __attribute__((always_inline)) {
+            if ((EOVAE_C8_ABL & 2) || !have_nx) return;
+            const int t = 2 * s + tt;
+            if (SUBPIX == 0) {
+              if (t < 4) { load_x_group(xt_tile, xc0, 2 * t); load_x_group(xt_tile, xc0, 2 * t + 1); }
+            } else if (ns == 2 && s == 0) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          if (2 * s + tt < nt) {   // uniform
-            if (!(EOVAE_C8_ABL & 16)) {
-              int ky, kx;
-              tap_of(cur, chunk, 2 * s + tt, ky, kx);
-              compute_tap(wslot + tt * WTAP, XDB ? (unsigned)(xbuf * XSET) : 0u, ky, kx);
+              for (int j = 0; j < 4; ++j) load_x_group(xt_tile, xc0, 4 * tt + j);
             }
-            if (tt == 0 && wave >= 4) stage_dma();
-            // halo groups of the staged chunk: two behind each of the taps 0..3; chunks with fewer taps
-            // issue what is left behind their last tap
-            if (!(EOVAE_C8_ABL & 2)) if (have_nx) {
-              const int t = 2 * s + tt;
-              if (SUBPIX == 0) {
-                if (t < 4) { load_x_group(xt_tile, xc0, 2 * t); load_x_group(xt_tile, xc0, 2 * t + 1); }
-              } else if (ns == 2 && s == 0) {   // conversion is in stage 1: everything behind taps 0 and 1
-#pragma unroll
-                for (int j = 0; j < 4; ++j) load_x_group(xt_tile, xc0, 4 * tt + j);
-              }
+          };
+          if (!(EOVAE_C8_ABL & 16)) {
+            Frag16 f16a;
+            Frag8 f8a;
+            load16(f16a, wslot, xsel, ky0, kx0);
+            load8(f8a, wslot, xsel, ky0, kx0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma16(f16a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) load16(f16a, wslot + WTAP, xsel, ky1, kx1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma8(f8a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave >= 4) stage_dma();
+            stage_loads(0);
+            if (two) {
+              load8(f8a, wslot + WTAP, xsel, ky1, kx1);
+              __builtin_amdgcn_sched_barrier(0);
+              mma16(f16a);
+              __builtin_amdgcn_sched_barrier(0);
+              mma8(f8a);
+              __builtin_amdgcn_sched_barrier(0);
+              stage_loads(1);
             }
+          } else {
+            if (wave >= 4) stage_dma();
+            stage_loads(0);
+            if (two) stage_loads(1);
           }
         }
         C8_STAMP(2);
@@ -636,6 +662,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     zero_acc();
 #if EOVAE_C8_STAMP
     C8_STAMP(7);
+    if (lane == 0 && blockIdx.x < C8_NBLK && rec < C8_MAXREC)   // 100 MHz wall clock next to the shader clock
+      c8_stamps[((blockIdx.x * 8 + wave) * C8_MAXREC + rec) * C8_NPT + 1] = __builtin_amdgcn_s_memrealtime();
     ++rec;
 #endif
     cur = nxt;
