@@ -174,9 +174,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (weak scaling)')
     ap.add_argument('--modality', default=None)
-    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help='cfg2 (default, headline): S2RGB train step L1+KL; cfg3: S2L2A 12-ch train step '
-                         'L1+MS-SSIM+KL; cfg5: S2L2A encode-only (encode_spatial_normalized + running stats)')
+                         'L1+MS-SSIM+KL; cfg4: mixed S2L2A / S1RTC random collate, batch 32 per rank (every rank '
+                         'draws its own modality per step); cfg5: S2L2A encode-only (encode_spatial_normalized + '
+                         'running stats)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -194,6 +196,8 @@ def main():
         args.modality = 'S2RGB' if args.workload == 'cfg2' else 'S2L2A'
     if args.workload == 'cfg5' and args.batch == 16:
         args.batch = 64
+    if args.workload == 'cfg4' and args.batch == 16:
+        args.batch = 32          # Lightning semantics: batch_size is per process (terramesh_datamodule.py:750)
     wl = WAVELENGTHS[args.modality]
     C = len(wl)
     model = build_model(C, msssim=args.workload == 'cfg3').to(device)
@@ -213,8 +217,24 @@ def main():
         driver = StepDriver(model, world)
     g = torch.Generator('cpu').manual_seed(1234 + rank)
     nb = 2  # distinct synthetic batches resident in HBM before the timed region
-    batches = [{'image': synthetic_images(args.batch, C, 256, g).to(device),
-                'wvs': torch.tensor(wl, device=device), 'modality': args.modality} for _ in range(nb)]
+    if args.workload == 'cfg4':
+        # BASELINE config 4: the random collate draws ONE modality per batch per process
+        # (terramesh_datamodule.py:418-503), so the ranks of one step run different channel counts.
+        # One resident batch per modality; step i of rank r uses the draw of random.Random(1234 + r + i).
+        import random
+        mods = ['S2L2A', 'S1RTC']
+        pool = {m: {'image': synthetic_images(args.batch, len(WAVELENGTHS[m]), 256, g).to(device),
+                    'wvs': torch.tensor(WAVELENGTHS[m], device=device), 'modality': m} for m in mods}
+        draws = [random.Random(1234 + rank + i).choice(mods) for i in range(args.warmup + args.steps)]
+
+        class _Draw:
+            def __getitem__(self, i):
+                return pool[draws[self.base + i]]
+        batches, nb = _Draw(), args.warmup + args.steps
+        batches.base = 0
+    else:
+        batches = [{'image': synthetic_images(args.batch, C, 256, g).to(device),
+                    'wvs': torch.tensor(wl, device=device), 'modality': args.modality} for _ in range(nb)]
 
     def sync():
         if world > 1:
@@ -224,6 +244,8 @@ def main():
     for i in range(args.warmup):
         driver.step(batches[i % nb], i)
     sync()
+    if args.workload == 'cfg4':
+        batches.base = args.warmup
     ops.CONV3X3_TIMER = ops.KernelTimer()
     # per-step HIP events on the compute stream (SURVEY 8d timing protocol: median and p10/p90
     # beside the barrier-bracketed wall time that `value` is computed from)
@@ -280,6 +302,9 @@ def main():
                                             '(L1 + 1e-6 KL, clip 1.0, Adam, cosine-warmup LR)',
                                     'cfg3': f'cfg3: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, full train step '
                                             '(L1 + MS-SSIM + 1e-6 KL, clip 1.0, Adam)',
+                                    'cfg4': f'cfg4: mixed S2L2A (12-ch) / S1RTC (2-ch) random collate, one modality per rank '
+                                            f'and step, 256x256, batch {args.batch}/GPU, full train step (L1 + 1e-6 KL, '
+                                            'clip 1.0, Adam)',
                                     'cfg5': f'cfg5: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, encode-only '
                                             '(encode_spatial_normalized + running latent statistics)'}[args.workload],
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',

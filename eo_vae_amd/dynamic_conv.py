@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 import torch.nn.init as init
+from torch.nn.attention import SDPBackend, sdpa_kernel
 
 from . import ops
 
@@ -127,7 +128,11 @@ class _DynamicBase(nn.Module):
                 self._remember(('id', id(wvs)), (wvs, wvs._version, out))
                 return out
         waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
-        out = self.weight_generator(self.fclayer(waves))
+        # The 4-head, <= 142-token self-attention of the generator runs on the MATH path of SDPA (two batched
+        # GEMMs + softmax): PyTorch's fused path on ROCm is aotriton, i.e. Triton-built kernels, which this
+        # product does not put into its step (north_star: no Triton); at this size there is nothing to fuse.
+        with sdpa_kernel(SDPBackend.MATH):
+            out = self.weight_generator(self.fclayer(waves))
         if cacheable:
             self._remember(vkey, out)
             self._remember(('id', id(wvs)), (wvs, wvs._version, out))

@@ -557,9 +557,18 @@ def gaussian_taps(sigma=1.5):
     return g / g.sum()
 
 
-def _ssim_cs(x, y, taps, c1, c2):
+# torchmetrics behaviour this restatement assumes (SURVEY 8c asks for it to be a named option): releases
+# >= 1.0 clamp the two variances at zero before forming cs / ssim (`torch.clamp(..., min=0.0)` in
+# functional/image/ssim.py::_ssim_update); earlier releases did not.  The product kernels follow the
+# default.  tests/test_oracle_golden.py cross-checks both settings against an independent fp64 / scipy
+# derivation; neither is a reference pin (torchmetrics is not installed here, not vendored, not pinned).
+MSSSIM_CLAMP_VARIANCE = True
+
+
+def _ssim_cs(x, y, taps, c1, c2, clamp_variance=None):
     """One scale: per-image mean SSIM and contrast-sensitivity. PARITY UNPINNED
     (restates torchmetrics.functional.image.ssim._ssim_update)."""
+    clamp_variance = MSSSIM_CLAMP_VARIANCE if clamp_variance is None else clamp_variance
     b, c, h, w = x.shape
     pad = (taps.numel() - 1) // 2
     xp = F.pad(x, (pad, pad, pad, pad), mode='reflect')
@@ -568,8 +577,9 @@ def _ssim_cs(x, y, taps, c1, c2):
     stack = torch.cat([xp, yp, xp * xp, yp * yp, xp * yp])
     out = F.conv2d(stack, k2d, groups=c).split(b)
     mx, my = out[0], out[1]
-    sxx = torch.clamp(out[2] - mx * mx, min=0.0)
-    syy = torch.clamp(out[3] - my * my, min=0.0)
+    sxx, syy = out[2] - mx * mx, out[3] - my * my
+    if clamp_variance:
+        sxx, syy = torch.clamp(sxx, min=0.0), torch.clamp(syy, min=0.0)
     sxy = out[4] - mx * my
     upper = 2 * sxy + c2
     lower = sxx + syy + c2
@@ -580,7 +590,7 @@ def _ssim_cs(x, y, taps, c1, c2):
     return ssim, cs
 
 
-def msssim(pred, target, data_range=6.0, betas=MSSSIM_BETAS, sigma=1.5):
+def msssim(pred, target, data_range=6.0, betas=MSSSIM_BETAS, sigma=1.5, clamp_variance=None):
     """Batch-mean MS-SSIM, normalize='relu' (consistency_loss.py:24-37 -> torchmetrics).
     PARITY UNPINNED: torchmetrics is not vendored/pinned/installed."""
     c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
@@ -588,7 +598,7 @@ def msssim(pred, target, data_range=6.0, betas=MSSSIM_BETAS, sigma=1.5):
     x, y = pred, target
     vals = []
     for s in range(len(betas)):
-        ssim, cs = _ssim_cs(x, y, taps, c1, c2)
+        ssim, cs = _ssim_cs(x, y, taps, c1, c2, clamp_variance)
         vals.append(torch.relu(ssim) if s == len(betas) - 1 else torch.relu(cs))
         x, y = F.avg_pool2d(x, 2), F.avg_pool2d(y, 2)
     stack = torch.stack(vals)  # [S, B]

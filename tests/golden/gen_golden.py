@@ -71,6 +71,16 @@ def ref_class_from_source(path, cls_name, ns):
     return ns[cls_name]
 
 
+def ref_defs_from_source(path, names, ns):
+    """Execute selected top-level class / function definitions of a reference script that cannot be
+    imported as a whole (same reason as ref_class_from_source)."""
+    tree = ast.parse(open(path).read())
+    nodes = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert len(nodes) == len(names), [n.name for n in nodes]
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), path, 'exec'), ns)
+    return [ns[n] for n in names]
+
+
 def npy(t):
     return t.detach().cpu().numpy().copy()   # a copy: running statistics are updated in place later
 
@@ -524,6 +534,31 @@ def running_stats():
     save('running_stats', **arrays)
 
 
+def batch_prep():
+    """N2: what the reference's collate does to a raw S2L2A batch -- Sentinel2L2ANorm (clip +
+    z-score, terramesh_datamodule.py:130-194), bilinear resize to target_size (:476-479), the D4 augmentation
+    (:347-369) -- run from the reference's own source for 8 seeded draws."""
+    print('batch preparation fixture')
+    import random
+    ns = {'torch': torch, 'nn': torch.nn, 'random': random}
+    Norm, aug = ref_defs_from_source(os.path.join(REF, 'eo_vae', 'datasets', 'terramesh_datamodule.py'),
+                                     ['Sentinel2L2ANorm', 'apply_batch_augmentations'], ns)
+    norm = Norm()
+    raw = hashed((2, 12, 20, 28), 811, 1.0) * 4000.0 + 3000.0      # spans below 0 and above 10000
+    arrays = {'raw': npy(raw), 'mean': npy(norm.mean.reshape(-1)), 'std': npy(norm.std.reshape(-1)),
+              'target_size': np.array([24, 32])}
+    x = norm(raw)
+    x = torch.nn.functional.interpolate(x, size=(24, 32), mode='bilinear', align_corners=False)
+    for seed in range(8):
+        random.seed(seed)
+        out = aug(x)
+        random.seed(seed)                       # replay the three draws the function made
+        hf, vf, k = random.random() > 0.5, random.random() > 0.5, random.randint(0, 3)
+        arrays[f'draw{seed}'] = np.array([int(hf), int(vf), k])
+        arrays[f'out{seed}'] = npy(out)
+    save('batch_prep', **arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
@@ -532,7 +567,8 @@ if __name__ == '__main__':
     groups = [('per_op', lambda: per_op(R)), ('whole_models', lambda: whole_models(R)),
               ('extra_losses', lambda: extra_losses(R)), ('eqvae', lambda: eqvae(R)),
               ('distill', lambda: distill(R)),
-              ('running_stats', running_stats), ('full_size', lambda: full_size(R))]
+              ('running_stats', running_stats), ('batch_prep', batch_prep),
+              ('full_size', lambda: full_size(R))]
     for name, fn in groups:
         if not only or name in only:
             fn()

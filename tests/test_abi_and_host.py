@@ -186,3 +186,51 @@ def test_generator_cache_is_keyed_on_wavelength_values():
         assert m._raw(w)[0] is a[0]
         w.copy_(torch.tensor(sets[1]))
         assert torch.equal(m._raw(w)[0], want[1][0])
+
+
+def test_from_pretrained_with_stubbed_hub(tmp_path, monkeypatch):
+    """from_pretrained (reference new_autoencoder.py:223-268): two hf_hub_download calls (config, checkpoint)
+    with the caller's repo / revision / cache arguments, then from_config on the two paths; ImportError when
+    huggingface_hub is absent."""
+    import builtins
+    import sys
+    import types
+    from eo_vae_amd.autoencoder import EOFluxVAE
+    cfg = tmp_path / 'model_config.yaml'
+    cfg.write_text("""
+model:
+  encoder: {_target_: eo_vae.models.Encoder, z_channels: 32, resolution: 64, in_channels: 3, ch: 32,
+            ch_mult: [1, 2], num_res_blocks: 1, use_dynamic_ops: true,
+            dynamic_conv_kwargs: {num_layers: 1, wv_planes: 64}}
+  decoder: {_target_: eo_vae.models.Decoder, z_channels: 32, resolution: 64, out_ch: 3, ch: 32,
+            ch_mult: [1, 2], num_res_blocks: 1, use_dynamic_ops: true,
+            dynamic_conv_kwargs: {num_layers: 1, wv_planes: 64}}
+""")
+    src = EOFluxVAE.from_config(str(cfg))
+    with torch.no_grad():
+        src.encoder.mid.attn_1.q.weight.fill_(0.125)
+    torch.save({'state_dict': src.state_dict()}, tmp_path / 'eo-vae.ckpt')
+    calls = []
+
+    def fake_download(repo_id, filename, revision=None, cache_dir=None, local_files_only=False, **kw):
+        calls.append((repo_id, filename, revision, cache_dir, local_files_only))
+        return str(tmp_path / filename)
+    stub = types.ModuleType('huggingface_hub')
+    stub.hf_hub_download = fake_download
+    monkeypatch.setitem(sys.modules, 'huggingface_hub', stub)
+    m = EOFluxVAE.from_pretrained('nilsleh/eo-vae', revision='abc', cache_dir=str(tmp_path), local_files_only=True)
+    assert [c[1] for c in calls] == ['model_config.yaml', 'eo-vae.ckpt']
+    assert all(c[0] == 'nilsleh/eo-vae' and c[2] == 'abc' and c[3] == str(tmp_path) and c[4] is True for c in calls)
+    assert not m.training and m.freeze_body is False
+    assert torch.all(m.encoder.mid.attn_1.q.weight == 0.125)
+    # without the package: ImportError, as the reference (:240-243)
+    monkeypatch.delitem(sys.modules, 'huggingface_hub')
+    real_import = builtins.__import__
+
+    def no_hub(name, *a, **k):
+        if name == 'huggingface_hub':
+            raise ImportError('no hub')
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(builtins, '__import__', no_hub)
+    with pytest.raises(ImportError, match='huggingface_hub'):
+        EOFluxVAE.from_pretrained('nilsleh/eo-vae')

@@ -128,3 +128,43 @@ def test_running_stats_merge_formula():
     assert torch.allclose(merged[1], ref.var, rtol=1e-4)
     assert torch.equal(merged[2], ref.min) and torch.equal(merged[3], ref.max)
     assert merged[4, 0] == ref.count[0]
+
+
+def _stats_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from eo_vae_amd.encode_latents import RunningStats
+    from eo_vae_amd.parallel import init_distributed
+    init_distributed('gloo')
+    g = torch.Generator().manual_seed(7 + rank)
+    z = torch.randn(6 + 3 * rank, 4, 5, 5, generator=g) * (1.0 + rank) + rank      # ragged per-rank sample counts
+    rs = RunningStats(4, 'cpu')
+    flat = z.permute(1, 0, 2, 3).reshape(4, -1)
+    rs.state = torch.stack([flat.mean(1), flat.var(1, unbiased=False), flat.amin(1), flat.amax(1),
+                            torch.full((4,), float(flat.shape[1]))])
+    rs.merge_across_ranks()
+    q.put((rank, z.numpy(), rs.state.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_running_stats_merge_across_ranks_world2():
+    """cfg5's one collective: all_gather of the per-rank (mean, var, min, max, count) + ordered Chan merges
+    (reference encode_latents.py:65-94 applied across ranks) must equal the statistics of the pooled data."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stats_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    pooled = torch.cat([torch.from_numpy(r[1]).permute(1, 0, 2, 3).reshape(4, -1) for r in res], dim=1).double()
+    for _, _, state in res:                      # every rank ends with the same merged state
+        st = torch.from_numpy(state).double()
+        assert torch.allclose(st[0], pooled.mean(1), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(st[1], pooled.var(1, unbiased=False), rtol=1e-4, atol=1e-6)
+        assert torch.equal(st[2], pooled.amin(1)) and torch.equal(st[3], pooled.amax(1))
+        assert torch.all(st[4] == pooled.shape[1])

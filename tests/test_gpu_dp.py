@@ -36,15 +36,17 @@ def _build(seed_fill=21):
     return m.cuda().train()
 
 
-def _batch(rank):
+def _batch(rank, mods=('S2L2A', 'S2L2A')):
+    """Rank r's batch; `mods[r]` is its modality (cfg4: the ranks of one step run DIFFERENT channel counts)."""
     from oracle import eo_vae_cpu as O
-    wvs = torch.tensor(O.WAVELENGTHS['S2L2A']).cuda()
-    x = O.synthetic_batch(2, 12, 64, seed=900 + rank).cuda()
+    wl = O.WAVELENGTHS[mods[rank % len(mods)]]
+    wvs = torch.tensor(wl).cuda()
+    x = O.synthetic_batch(2, len(wl), 64, seed=900 + rank).cuda()
     eps = torch.randn(2, 32, 8, 8, generator=torch.Generator().manual_seed(50 + rank)).cuda()
     return {'image': x, 'wvs': wvs}, eps
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mods=('S2L2A', 'S2L2A')):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK='0', EOVAE_DIST_BACKEND='gloo', EOVAE_ALL_RANKS_ONE_GPU='1')
     import torch.distributed as dist
@@ -63,7 +65,7 @@ def _worker(rank, world, port, q):
     t = T()
     t.reducer.broadcast_parameters([b for b in m.buffers() if b.is_floating_point()])
     m.attach(t, [opt], [])
-    batch, eps = _batch(rank)
+    batch, eps = _batch(rank, mods)
     m.training_step(batch, 0, noise=eps)
     torch.cuda.synchronize()
     q.put((rank, opt.flat.grad.cpu().numpy(), opt.flat.data.cpu().numpy(), len(t.reducer.buckets)))
@@ -72,11 +74,17 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_train_step_on_one_gpu():
+@pytest.mark.parametrize('mods', [('S2L2A', 'S2L2A'), ('S2L2A', 'S1RTC')], ids=['same-modality', 'cfg4-mixed'])
+def test_two_rank_train_step_on_one_gpu(mods):
+    """cfg4-mixed = BASELINE config 4: the random collate draws ONE modality per batch per process
+    (reference terramesh_datamodule.py:418-503), so in the same step rank 0 runs 12 channels (S2L2A) and
+    rank 1 runs 2 (S1RTC).  Every parameter shape is channel-count independent, so the bucket launch order
+    and the all-reduce are well formed; the replicas must stay bit-identical and the averaged gradient must
+    equal the single-process average of the two ranks' gradients."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mods)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
@@ -93,7 +101,7 @@ def test_two_rank_train_step_on_one_gpu():
         m = _build(21)
         opts = m.configure_optimizers()
         opt = opts[0] if isinstance(opts, (list, tuple)) else opts
-        batch, eps = _batch(r)
+        batch, eps = _batch(r, mods)
         recon, post = m(batch['image'], batch['wvs'], noise=eps)
         opt.zero_grad()
         loss, _ = m.loss_fn(inputs=batch['image'], wvs=batch['wvs'], reconstructions=recon)
@@ -156,3 +164,26 @@ def test_rccl_world_of_one_matches_plain_step():
     # AVG over one rank is the identity: only wgrad's atomic ordering differs between the two runs;
     # the first Adam steps move every entry by ~lr whatever |g| is, so compare in units of lr = 1e-3
     assert (pa - pb).abs().max() < 2.5e-3 and ((pa - pb).abs() > 2e-4).float().mean() < 0.01
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_with_two_ranks():
+    """bench.py through torch.distributed.run, exactly as the driver starts the N > 1 points (2 ranks sharing
+    the one GPU of a test box over gloo): one JSON line from rank 0, n_gpus = 2, whole-job throughput."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EOVAE_DIST_BACKEND='gloo', EOVAE_ALL_RANKS_ONE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2',
+           '--steps', '2', '--warmup', '1', '--batch', '2', '--workload', 'cfg4']
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+    assert 'cfg4' in d['config']['workload'] and d['value'] > 0
+    assert abs(d['value'] - 4 * 1000.0 / d['ms_per_step']) < 1e-2 * d['value']

@@ -327,6 +327,27 @@ def test_batch_prep_matches_reference_ops(hs, ws, ht, wt, prec):
                 assert (out.cpu() - r).abs().max().item() < 2e-5, (hf, vf, k)
 
 
+def test_batch_prep_against_reference_fixture(golden, prec):
+    """N2 pinned by the reference itself: tests/golden/batch_prep.npz was produced by running
+    Sentinel2L2ANorm + F.interpolate + apply_batch_augmentations FROM the reference's source
+    (terramesh_datamodule.py:130-194, 347-369, 476-479; gen_golden.py batch_prep) for 8 seeded D4 draws."""
+    from eo_vae_amd.data import S2L2A_MEAN, S2L2A_STD, prepare_batch
+    g = golden('batch_prep')
+    assert np.allclose(np.asarray(S2L2A_MEAN, dtype=np.float32), g['mean']) and \
+        np.allclose(np.asarray(S2L2A_STD, dtype=np.float32), g['std'])     # the product's table = the reference's
+    raw = T(g['raw']).cuda()
+    th, tw = (int(v) for v in g['target_size'])
+    seen = set()
+    for seed in range(8):
+        hf, vf, k = (int(v) for v in g[f'draw{seed}'])
+        seen.add((hf, vf, k))
+        out = prepare_batch(raw, S2L2A_MEAN, S2L2A_STD, (0.0, 10000.0), (th, tw), bool(hf), bool(vf), k)
+        want = T(g[f'out{seed}'])
+        assert tuple(out.shape) == tuple(want.shape)
+        assert (out.cpu() - want).abs().max().item() < 2e-5, (seed, hf, vf, k)
+    assert len(seen) >= 5      # the seeds cover several distinct D4 elements
+
+
 def test_encode_pairs_npz_contract(tmp_path, prec):
     """N1: per-AOI .npz files + latent_stats.json in the reference's layout (encode_latents.py:345-352,
     521-530)."""

@@ -63,6 +63,22 @@ def test_tiny_eval_api_against_golden_and_oracle(golden):
         assert rel(prod.reconstruct(xg, wg), oracle.reconstruct(x, wvs)) < REL_OUT
 
 
+def test_decode_raw_is_the_bare_decoder(golden):
+    """decode_raw (reference new_autoencoder.py:431-438): the decoder applied to an already shuffled,
+    un-normalised latent -- no inverse BatchNorm, no pixel shuffle -- against the oracle."""
+    from oracle import eo_vae_cpu as O
+    oracle, prod = build_pair(O.TINY, 21)
+    oracle.eval(), prod.eval()
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    z = O._hash_uniform(2 * 32 * 8 * 8, 77).reshape(2, 32, 8, 8).float() * 3.0
+    with torch.no_grad():
+        want = oracle.decoder(z, wvs)
+        got = prod.decode_raw(z.cuda(), wvs.cuda())
+    assert tuple(got.shape) == (2, 3, 64, 64)
+    assert rel(got, want) < REL_OUT
+    assert rel(got, prod.decoder(z.cuda(), wvs.cuda())) == 0.0
+
+
 def test_tiny_train_forward_backward(golden):
     """One train-mode forward/backward: recon, KL, every parameter gradient vs the oracle.
     The gradient comparison uses the smooth Charbonnier loss (the reference config's

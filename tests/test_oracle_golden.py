@@ -250,3 +250,63 @@ def test_eqvae_branches(golden):
             for k, p in vae.named_parameters():
                 if p.grad is not None:
                     assert abs(p.grad.norm().item() - gn[k]) <= 2e-3 * top, k
+
+
+def _msssim_scipy(pred, target, data_range=6.0, betas=O.MSSSIM_BETAS, sigma=1.5, clamp=True):
+    """Second, independent derivation of the torchmetrics MS-SSIM semantics in float64 on
+    scipy.ndimage: separable `correlate1d(mode='mirror')` (= reflect padding without the edge sample, what
+    F.pad(mode='reflect') does) over the whole image, then the 5-pixel crop.  Not a reference pin -- a check
+    that the oracle's conv2d / padding / cropping / pooling bookkeeping says what the description says."""
+    from scipy.ndimage import correlate1d
+    k = 2 * int(3.5 * sigma + 0.5) + 1
+    assert k == 11                                   # kernel_size=5 of consistency_loss.py:32 is ignored
+    d = np.arange(k, dtype=np.float64) - (k - 1) / 2
+    taps = np.exp(-0.5 * (d / sigma) ** 2)
+    taps /= taps.sum()
+    pad = (k - 1) // 2
+    blur = lambda a: correlate1d(correlate1d(a, taps, axis=-1, mode='mirror'), taps, axis=-2, mode='mirror')  # noqa: E731
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    x, y = pred.double().numpy(), target.double().numpy()
+    per_scale = []
+    for s in range(len(betas)):
+        mx, my = blur(x), blur(y)
+        sxx, syy, sxy = blur(x * x) - mx * mx, blur(y * y) - my * my, blur(x * y) - mx * my
+        if clamp:
+            sxx, syy = np.maximum(sxx, 0.0), np.maximum(syy, 0.0)
+        cs_map = (2 * sxy + c2) / (sxx + syy + c2)
+        ssim_map = (2 * mx * my + c1) / (mx * mx + my * my + c1) * cs_map
+        crop = (Ellipsis, slice(pad, -pad), slice(pad, -pad))
+        cs = cs_map[crop].reshape(x.shape[0], -1).mean(-1)
+        ssim = ssim_map[crop].reshape(x.shape[0], -1).mean(-1)
+        per_scale.append((ssim, cs))
+        b, c, h, w = x.shape
+        x = x.reshape(b, c, h // 2, 2, w // 2, 2).mean((3, 5))      # avg_pool2d(2)
+        y = y.reshape(b, c, h // 2, 2, w // 2, 2).mean((3, 5))
+    vals = [np.maximum(cs, 0.0) for _, cs in per_scale[:-1]] + [np.maximum(per_scale[-1][0], 0.0)]
+    out = np.prod(np.stack(vals) ** np.asarray(betas)[:, None], axis=0).mean()
+    return out, per_scale
+
+
+@pytest.mark.parametrize('clamp', [True, False])
+def test_msssim_against_independent_scipy_derivation(clamp):
+    """VERDICT r1 item 8 / ADVICE: cross-check oracle.msssim per scale (cs, ssim) and in total against a second
+    from-scratch float64 implementation, for both settings of the version-sensitive variance clamp."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    x = O.synthetic_batch(2, 3, 192, seed=5)
+    y = x + 0.3 * torch.randn(x.shape, generator=g) * (1.0 + x.abs())       # correlated but clearly different
+    want, per_scale = _msssim_scipy(y, x, clamp=clamp)
+    got = O.msssim(y.double(), x.double(), clamp_variance=clamp).item()
+    assert 0.05 < want < 0.98                                               # a non-degenerate case
+    assert abs(got - want) < 1e-6 * max(1.0, abs(want))      # (the oracle builds its taps in float32: ~1e-8)
+    taps = O.gaussian_taps(1.5).double()
+    assert taps.numel() == 11
+    xs, ys = y.double(), x.double()
+    for s, (ssim_w, cs_w) in enumerate(per_scale):
+        ssim_o, cs_o = O._ssim_cs(xs, ys, taps, (0.01 * 6.0) ** 2, (0.03 * 6.0) ** 2, clamp)
+        assert np.allclose(ssim_o.numpy(), ssim_w, rtol=1e-6, atol=1e-9), s
+        assert np.allclose(cs_o.numpy(), cs_w, rtol=1e-6, atol=1e-9), s
+        xs, ys = F.avg_pool2d(xs, 2), F.avg_pool2d(ys, 2)
+    # flat patches make the variance estimate round to tiny negatives: there the two settings may differ
+    flat = torch.full((1, 2, 176, 176), 0.25, dtype=torch.float64)
+    assert abs(O.msssim(flat, flat.clone(), clamp_variance=clamp).item() - 1.0) < 1e-6
