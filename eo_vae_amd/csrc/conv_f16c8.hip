@@ -710,6 +710,7 @@ struct WgCArgs {
   int mode;
   int tiles_x, tiles_y, ntiles, ncib;
   int subpix, creal, cpb;   // as WgBArgs (conv_bf16x3.hip)
+  int ncob_, split, xcd_remap;
 };
 
 template <int SUBPIX>
@@ -730,7 +731,24 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
   const int ct = wave & 3, cih = wave >> 2;
-  const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
+  // XCD-aware block -> (slab, tile stride slot) map.  Workgroups are dealt round-robin to the 8 XCDs, each with
+  // its own L2.  The slabs (co-block x ci-block) that walk the SAME pixel tiles -- ncib of them share every dY
+  // tile, ncob every X tile -- are given consecutive slots of ONE XCD, so a shared tile is fetched into one L2
+  // once instead of into up to 8 of them (r1: wgrad L2-miss fetch 1.8x .. 3.4x the algorithmic bytes).
+  int slab, ysub;
+  {
+    const int nslab = a.ncib * a.ncob_;
+    const int b = blockIdx.x;
+    if (a.xcd_remap) {
+      const int xcd = b & 7, q = b >> 3;
+      slab = q % nslab;
+      ysub = (q / nslab) * 8 + xcd;
+    } else {
+      slab = b % nslab;
+      ysub = b / nslab;
+    }
+  }
+  const int cib = slab % a.ncib, cob = slab / a.ncib;
   const int par = SUBPIX == 1 ? cob / a.cpb : (SUBPIX == 2 ? (cib * 64) / a.creal : 0);
   const int py = par >> 1, px = par & 1;
   const int dych = SUBPIX == 1 ? a.creal : a.Cout;   // channels / plane of the stored dy tensor
@@ -1056,7 +1074,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     auto load = [&](int tile, int hf) __attribute__((always_inline)) {
       if constexpr (FULL) issue_fast(tile, hf); else issue(tile, hf);
     };
-    int tile = blockIdx.y;
+    int tile = ysub;
     if (tile < a.ntiles) {
 #pragma unroll 1
       for (int hf = 0; hf < 2; ++hf) {
@@ -1066,8 +1084,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     }
     __syncthreads();
     int cur = 0;
-    for (; tile < a.ntiles; tile += gridDim.y) {
-      const int next = tile + gridDim.y;
+    for (; tile < a.ntiles; tile += a.split) {
+      const int next = tile + a.split;
       const bool has_next = next < a.ntiles;
       const unsigned char* base = smem + cur * BUF;
 #pragma unroll 1
@@ -1354,7 +1372,9 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
   int split = EOVAE_WGRAD_BLOCKS / (a.ncib * ncob);   // one block per CU (conv_bf16x3.hip)
   if (split < 1) split = 1;
   if (split > a.ntiles) split = a.ntiles;
-  dim3 grid(a.ncib * ncob, split);
+  a.ncob_ = ncob; a.split = split;
+  a.xcd_remap = (a.ncib * ncob > 1 && split % 8 == 0) ? 1 : 0;
+  dim3 grid(a.ncib * ncob * split);
   hipStream_t st = (hipStream_t)stream;
   if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1>), grid, dim3(512), 0, st, a);
   else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2>), grid, dim3(512), 0, st, a);

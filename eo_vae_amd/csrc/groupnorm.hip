@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ stats, const float* __restrict__ gm,
     const float* __restrict__ dx_add, float* __restrict__ dx, int C, int HW, int cpg, int chunks,
-    unsigned* __restrict__ amax_bits) {
+    float* __restrict__ amax_part) {
   const int plane = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-  float amax = 0.f;   // max |dx| of this block (only reported when amax_bits is given)
+  float amax = 0.f;   // max |dx| of this wave (reported when amax_part is given)
   const int c = plane % C, n = plane / C;
   const int ng = n * (C / cpg) + c / cpg;
   const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
@@ -234,14 +234,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
       dx[base + i] = o;
     }
   }
-  // max |dx| for the f16c8 data-gradient pre-scale (conv_f16c8.hip): float bits order like the floats; the
-  // running maximum is read first, so that after the first few blocks almost none issues an atomic
-  if (amax_bits) {
+  // max |dx| for the f16c8 data-gradient pre-scale (conv_f16c8.hip): one plain store per wave into a partial
+  // array that amax_fold_kernel folds afterwards.  (Atomics on one word cost 0.65 ms per launch when every wave
+  // issued one, and a read-then-maybe-atomic kept every wave resident behind its own stores: +37 %.)
+  if (amax_part) {
     amax = wave_max(amax);
-    const unsigned bits = __builtin_bit_cast(unsigned, amax);
-    if ((threadIdx.x & 63) == 0 && amax < 3.0e38f && bits > *reinterpret_cast<volatile unsigned*>(amax_bits))
-      atomicMax(amax_bits, bits);
+    if ((threadIdx.x & 63) == 0) amax_part[blockIdx.x * 4 + (threadIdx.x >> 6)] = amax;
   }
+}
+
+// out_bits = float bits of max(part[0..n)): 16 blocks, one atomic per wave (out_bits pre-zeroed)
+__global__ __launch_bounds__(256) void amax_fold_kernel(const float* __restrict__ part, int n,
+                                                        unsigned* __restrict__ out_bits) {
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmaxf(m, part[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
 }
 
 int nsplit_for(size_t gsize) {
@@ -268,7 +276,8 @@ extern "C" {
 size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G) {
   size_t gsize = (size_t)(C / G) * HW;
   size_t fwd = (size_t)N * G * nsplit_for(gsize) * 2 * sizeof(double);
-  size_t bwd = (size_t)N * C * 2 * sizeof(double) + (size_t)N * G * 2 * sizeof(float);
+  size_t bwd = (size_t)N * C * 2 * sizeof(double) + (size_t)N * G * 2 * sizeof(float) +
+               (size_t)N * C * chunks_for(HW) * 4 * sizeof(float);   // + per-wave max|dx| partials
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -322,12 +331,15 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
     eovae_set_error("gn_silu_bwd: memset failed");
     return EOVAE_ERR_LAUNCH;
   }
+  float* part = dx_amax_bits ? gm + (size_t)N * G * 2 : nullptr;
   if (silu)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
-                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks, dx_amax_bits);
+                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks, part);
   else
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
-                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks, dx_amax_bits);
+                       gamma, beta, stats, gm, dx_add, dx, C, HW, cpg, chunks, part);
+  if (dx_amax_bits)
+    hipLaunchKernelGGL(amax_fold_kernel, dim3(16), dim3(256), 0, st, part, N * C * chunks * 4, dx_amax_bits);
   EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd");
   return EOVAE_OK;
 }
