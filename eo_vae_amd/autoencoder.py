@@ -253,6 +253,32 @@ class EOFluxVAE(LightningModule):
     def decode_raw(self, z, wvs):
         return self.decoder(z, wvs)
 
+    # Posterior noise, prefetched.  The reference draws it from the CPU default generator inside sample()
+    # (distributions.py:44-46) and copies it from pageable memory: a blocking copy that makes the host wait for
+    # the encoder and leaves the GPU idle (~3 ms per step) until the host has caught up again.  Here the SAME
+    # draw (same generator, same number stream: nothing else consumes it in between) is made before the
+    # encoder is enqueued, into one of two pinned buffers, and copied without blocking.
+    _lat_geom = None          # (z_channels, downsample factor y, x), learnt on the first sampled forward
+    _noise_slots = None
+
+    def _prefetch_noise(self, x):
+        if self._lat_geom is None or not x.is_cuda:
+            return None
+        z, fy, fx = self._lat_geom
+        shape = (x.shape[0], z, x.shape[2] // fy, x.shape[3] // fx)
+        if self._noise_slots is None or self._noise_slots['shape'] != shape:
+            self._noise_slots = {'shape': shape, 'i': 0, 'ev': [None, None],
+                                 'buf': [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2)]}
+        st = self._noise_slots
+        i = st['i'] = st['i'] ^ 1
+        if st['ev'][i] is not None:
+            st['ev'][i].synchronize()       # the copy that last read this buffer has run
+        torch.randn(shape, out=st['buf'][i])
+        dev = st['buf'][i].to(x.device, non_blocking=True)
+        st['ev'][i] = torch.cuda.Event()
+        st['ev'][i].record()
+        return dev
+
     def noising(self, x):
         sigma = self.noise_tau * torch.rand((x.size(0),) + (1,) * (x.dim() - 1), device=x.device)
         return x + sigma * torch.randn_like(x)
@@ -261,7 +287,12 @@ class EOFluxVAE(LightningModule):
                 noise: torch.Tensor | None = None):
         """encode -> sample/mode -> (EQ-VAE transform) -> shuffle+BN -> inverse BN+unshuffle -> decode.
         `noise` (optional, beyond the reference signature) injects the posterior noise."""
+        if sample_posterior and noise is None:
+            noise = self._prefetch_noise(x)
         posterior = self.encode(x, wvs)
+        if sample_posterior and self._lat_geom is None:
+            m = posterior.parameters
+            self._lat_geom = (m.shape[1] // 2, x.shape[2] // m.shape[2], x.shape[3] // m.shape[3])
         z = posterior.sample(noise) if sample_posterior else posterior.mode()
         if scale is not None or angle is not None:  # EQ-VAE: bilinear scale + rot90 in ONE gather kernel
             size = self._scaled_size(z, scale) if scale is not None else z.shape[-2:]
