@@ -925,16 +925,19 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pixl = tid & 15, quad = tid >> 4;
-      typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
       typedef short s16x2 __attribute__((ext_vector_type(2)));
-      f16x4v hi;
       float v[4], lo[4];
+      int hp[2];   // 4 x f16, converted and subtracted with 3.5 VALU instructions per element (see convert_store_x)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; j += 2) {
         v[j] = dyr[i][j] * dys;
-        hi[j] = (_Float16)v[j];
-        lo[j] = v[j] - (float)hi[j];
+        v[j + 1] = dyr[i][j + 1] * dys;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp[j >> 1]) : "v"(v[j]), "v"(v[j + 1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hp[j >> 1]), "v"(v[j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hp[j >> 1]), "v"(v[j + 1]));
       }
+      i32x2 hi;
+      hi[0] = hp[0]; hi[1] = hp[1];
       s16x2 l8v = {0, 0};
       l8v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l8v, lo[0], lo[1], 0x1p-12f, false);
       l8v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l8v, lo[2], lo[3], 0x1p-12f, true);
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       h8v = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h8v, true);
       const int ks = 2 * hf + i;
       const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
-      *reinterpret_cast<f16x4v*>(base + off) = hi;
+      *reinterpret_cast<i32x2*>(base + off) = hi;
       const int off8 = OFF_D8 + (quad >> 3) * (64 * 32) + (ks * 16 + pixl) * 32 + (quad & 7) * 4;
       *reinterpret_cast<int*>(base + off8) = __builtin_bit_cast(int, l8v);   // image 0: dyl'
       *reinterpret_cast<int*>(base + off8 + D8IMG) = h8v;                    // image 1: dyh'
@@ -958,12 +961,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         const int t2 = hf * XHALF + tt;
         const int oct = t2 / NXP, pix = t2 - oct * NXP;
         typedef short s16x2 __attribute__((ext_vector_type(2)));
-        f16x8 hi;
+        i32x4 hi;
         float lo[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          hi[j] = (_Float16)xr[i][j];
-          lo[j] = xr[i][j] - (float)hi[j];
+        for (int j = 0; j < 8; j += 2) {
+          int hp;
+          asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(xr[i][j]), "v"(xr[i][j + 1]));
+          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hp), "v"(xr[i][j]));
+          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hp), "v"(xr[i][j + 1]));
+          hi[j >> 1] = hp;
         }
         s16x2 l0 = {0, 0}, l1 = {0, 0};
         l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][4], xr[i][5], 0, false);
         h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][6], xr[i][7], h1, true);
         const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
-        *reinterpret_cast<f16x8*>(base + off) = hi;
+        *reinterpret_cast<i32x4*>(base + off) = hi;
         const int off8 = OFF_X8 + (oct >> 2) * (NXP * 32) + pix * 32 + (oct & 3) * 8;
         i32x2 hv, lv;
         hv[0] = h0; hv[1] = h1;
