@@ -1097,15 +1097,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
 #pragma unroll 1
       for (int hf = 0; hf < 2; ++hf) {
         if (has_next) load(next, hf);
-#pragma unroll 1
-        for (int sub = 0; sub < 2; ++sub) compute(base, 2 * hf + sub);
-        // The staged half tile is committed BEFORE the row's fp8 products: its 24 staging registers and the
-        // 16 fragment registers of the scaled MFMAs do not fit beside 144 accumulators at the same time
-        // (230 spilled VGPRs otherwise).  Scheduling fences keep the compiler from undoing the order.
-        if (has_next) commit(cur ^ 1, hf);
+        // the row's fp8 products first, then its two f16 k-steps, then the commit: the loads above have all 54
+        // MFMAs of the half tile (2304 cycles per wave) to land.  (With the commit between the two groups of
+        // MFMAs chosen by the compiler the register allocator spilled 230 VGPRs; scheduling fences keep this
+        // order.  Staggering the commit between waves 0-3 and 4-7 -- SQ counters show VALU 2 x 23 % and MFMA
+        // 38 % of a SIMD's cycles adding up -- spilled 498 in either arrangement tried.)
         __builtin_amdgcn_sched_barrier(0);
         compute8(base, hf);   // the row's two k-steps share one K = 64 correction product per tap
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int sub = 0; sub < 2; ++sub) compute(base, 2 * hf + sub);
+        if (has_next) commit(cur ^ 1, hf);
       }
       __syncthreads();
       cur ^= 1;
