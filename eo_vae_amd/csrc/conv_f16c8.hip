@@ -55,6 +55,7 @@ struct ConvCArgs {
   int subpix, creal, cpb;    // as ConvBArgs (conv_bf16x3.hip)
   int xcd_remap;
   int ntiles;                // tiles x co-blocks walked by the persistent grid
+  int packed;                // x = f16c8 operand records (GroupNorm-apply, forward only)
 };
 
 // power of two 2^k as a float, k clamped to the normal range
@@ -86,6 +87,8 @@ __device__ __forceinline__ int wincnt(int pb) {
 // converts while its partner multiplies) and written to the single halo buffer between the two
 // barriers that end the chunk.  Weights arrive by LDS-DMA, two taps per stage, into the other half of
 // a 4-slot ring.  A tile's epilogue runs with the next tile's first chunk already staged.
+// PACKED: x is not fp32 NCHW but the operand records GroupNorm-apply wrote (groupnorm.hip: 32 B per pixel and
+// channel octet = 8 f16 | 8 lo' | 8 hi'): a task is two 16-byte loads and three LDS stores, no conversion.
 // Diagnostic build only (-DEOVAE_C8_STAMP=1, tools/c8_stamps.py): shader-clock stamps per pipeline stage of
 // the first blocks, written to a buffer nothing else reads.  The product build has no stamp code.
 #ifndef EOVAE_C8_STAMP
@@ -107,7 +110,7 @@ __device__ unsigned long long c8_stamps[C8_NBLK * 8 * C8_MAXREC * C8_NPT];
 #ifndef EOVAE_C8_ABL
 #define EOVAE_C8_ABL 0   // timing-only experiments: 1 few stores, 2 no halo loads, 4 no conversion, 8 no weight DMA, 16 no MFMAs
 #endif
-template <int TH, int SUBPIX>
+template <int TH, int SUBPIX, bool PACKED>
 __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   constexpr int NW = 8, TW = 32, BM = 128, KC = 32, NTHR = NW * 64;
   constexpr int XH = TH + 2, XW = TW + 2, NPX = XH * XW;
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       }
       xokm |= (si >= 0 ? 1u : 0u) << i;
       // BYTE offset: scalar base + 32-bit lane offset is one instruction (saddr form), no 64-bit lane address
-      xoff[i] = 4u * ((unsigned)((tk < XTASKS ? g : 0) * 8) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0));
+      xoff[i] = PACKED ? 32u * ((unsigned)(tk < XTASKS ? g : 0) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0))
+                       : 4u * ((unsigned)((tk < XTASKS ? g : 0) * 8) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0));
     }
   };
   // UNCONDITIONAL loads from clamped addresses; validity is applied at conversion (conv_bf16x3.hip).
@@ -234,6 +238,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       const int par = c0 / a.creal;
       cbase = c0 - par * a.creal;
       poff = (par >> 1) * a.Win + (par & 1);
+    }
+    if (PACKED) {   // group j (0, 1) = the j-th 16 bytes of every task's record
+      const char* cj = reinterpret_cast<const char*>(a.x) +
+                       (((size_t)t.n * (xch / 8) + cbase / 8) * in_plane) * 32 + 16 * j;
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(cj + xoff[i]);
+        xr[i][4 * j] = q[0]; xr[i][4 * j + 1] = q[1]; xr[i][4 * j + 2] = q[2]; xr[i][4 * j + 3] = q[3];
+      }
+      return;
     }
     const char* cj = reinterpret_cast<const char*>(a.x + ((size_t)t.n * xch + cbase + j) * in_plane + poff);
 #pragma unroll
@@ -257,6 +271,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     unsigned char* xsm = smem + xb * XSET;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
+      if (PACKED) {   // records are stored as they are; a halo pixel outside the image is an all-zero record
+        const int keep = ((xokm >> i) & 1) ? -1 : 0;
+        if (xst16[i] != ~0u) {
+          i32x4 hv;
+          i32x2 lv, uv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hv[k] = __builtin_bit_cast(int, xr[i][k]) & keep;
+          lv[0] = __builtin_bit_cast(int, xr[i][4]) & keep; lv[1] = __builtin_bit_cast(int, xr[i][5]) & keep;
+          uv[0] = __builtin_bit_cast(int, xr[i][6]) & keep; uv[1] = __builtin_bit_cast(int, xr[i][7]) & keep;
+          *reinterpret_cast<i32x4*>(xsm + xst16[i]) = hv;
+          *reinterpret_cast<i32x2*>(xsm + xst8[i]) = lv;
+          *reinterpret_cast<i32x2*>(xsm + xst8[i] + 2 * NPX * 16) = uv;
+        }
+        continue;
+      }
       const float sm = ((xokm >> i) & 1) ? xs : 0.f;   // validity folded into the scale
       typedef short s16x2 __attribute__((ext_vector_type(2)));
       float v[8], lo[8];
@@ -529,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   setup_x(cur);
   dma_w(cur, 0, 0, 0);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) load_x_group(cur, 0, j);
+  for (int j = 0; j < (PACKED ? 2 : 8); ++j) load_x_group(cur, 0, j);
   if (XDB) {
     convert_store_x(0);
   } else {
@@ -575,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
         // (VALU) while its partner multiplies
         if (SUBPIX != 0 && ns == 1 && have_nx) {   // single-stage chunks (stride-2 forms): loaded and converted at once
 #pragma unroll
-          for (int j = 0; j < 8; ++j) load_x_group(xt_tile, xc0, j);
+          for (int j = 0; j < (PACKED ? 2 : 8); ++j) load_x_group(xt_tile, xc0, j);
         }
         if (!(EOVAE_C8_ABL & 4)) if (s == cs && have_nx && wave < 4) {
           if (XDB) convert_store_x(xbuf ^ 1); else convert_x();
@@ -593,7 +622,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
           auto stage_loads = [&](int tt) __attribute__((always_inline)) {
             if ((EOVAE_C8_ABL & 2) || !have_nx) return;
             const int t = 2 * s + tt;
-            if (SUBPIX == 0) {
+            if (PACKED) {
+              if (t < 2) load_x_group(xt_tile, xc0, t);      // two 16-byte groups, behind taps 0 and 1
+            } else if (SUBPIX == 0) {
               if (t < 4) { load_x_group(xt_tile, xc0, 2 * t); load_x_group(xt_tile, xc0, 2 * t + 1); }
             } else if (ns == 2 && s == 0) {
 #pragma unroll
@@ -642,7 +673,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
         }
         C8_STAMP(6);
         // plain path: stages 0 and 1 each issued 4 groups behind their DMAs
-        if (SUBPIX == 0 && s < 2 && !(EOVAE_C8_ABL & 2)) {
+        if (PACKED && s == 0 && !(EOVAE_C8_ABL & 2)) {          // stage 0 issued both 16-byte groups behind its DMAs
+          if (have_nx) stage_barrier(std::integral_constant<int, 2 * LPG>{}); else stage_barrier(IC0{});
+        } else if (!PACKED && SUBPIX == 0 && s < 2 && !(EOVAE_C8_ABL & 2)) {
           if (have_nx) stage_barrier(std::integral_constant<int, 4 * LPG>{}); else stage_barrier(IC0{});
         } else {
           stage_barrier(IC0{});
@@ -713,7 +746,9 @@ struct WgCArgs {
   int ncob_, split, xcd_remap;
 };
 
-template <int SUBPIX>
+// XPACKED: x is the f16c8 operand-record tensor GroupNorm-apply wrote (32 B per pixel and channel octet): an X task is
+// two 16-byte loads and three LDS stores, no conversion (plain layers only: SUBPIX 0, mode NORMAL, Cin % 64 == 0).
+template <int SUBPIX, bool XPACKED>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   constexpr int NT = SUBPIX ? 4 : 9;  // accumulated taps: all 9, or the parity's 2x2 support
   constexpr int PW = 32, XW = 40, XWV = 34, NXP = 4 * XW;  // 2 output rows + halo; LDS row pitch 40
@@ -842,12 +877,23 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
           }
         }
         const int xch = SUBPIX == 2 ? a.creal : a.Cin;
+        if (XPACKED) {
+          const char* rec = reinterpret_cast<const char*>(a.x) +
+                            (((size_t)n * (a.Cin / 8) + cib * 8 + oct) * in_plane + (si >= 0 ? si : 0)) * 32;
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(rec), q1 = *reinterpret_cast<const f32x4*>(rec + 16);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ci = cib * 64 + oct * 8 + j;
-          xr[i][j] = (si >= 0 && ci < a.Cin)
-                         ? a.x[((size_t)n * xch + (ci - (SUBPIX == 2 ? par * a.creal : 0))) * in_plane + si]
-                         : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            xr[i][j] = si >= 0 ? q0[j] : 0.f;
+            xr[i][4 + j] = si >= 0 ? q1[j] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ci = cib * 64 + oct * 8 + j;
+            xr[i][j] = (si >= 0 && ci < a.Cin)
+                           ? a.x[((size_t)n * xch + (ci - (SUBPIX == 2 ? par * a.creal : 0))) * in_plane + si]
+                           : 0.f;
+          }
         }
       }
     }
@@ -903,8 +949,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       m |= (si >= 0 ? 1u : 0u) << (2 + i);
       const float* src = xn + (size_t)(oct * 8) * in_plane + (si >= 0 ? si : 0);
       if (i == 0 || tid < XHALF - 512) {   // second round: 128 of the 512 threads
+        if (XPACKED) {
+          const char* rec = reinterpret_cast<const char*>(a.x) +
+                            (((size_t)n * (a.Cin / 8) + cib * 8 + oct) * in_plane + (si >= 0 ? si : 0)) * 32;
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(rec), q1 = *reinterpret_cast<const f32x4*>(rec + 16);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xr[i][j] = src[(size_t)j * in_plane];
+          for (int j = 0; j < 4; ++j) { xr[i][j] = q0[j]; xr[i][4 + j] = q1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xr[i][j] = src[(size_t)j * in_plane];
+        }
       }
     }
     vmask = m;
@@ -962,24 +1016,35 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         const int oct = t2 / NXP, pix = t2 - oct * NXP;
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         i32x4 hi;
-        float lo[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          int hp;
-          asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(xr[i][j]), "v"(xr[i][j + 1]));
-          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hp), "v"(xr[i][j]));
-          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hp), "v"(xr[i][j + 1]));
-          hi[j >> 1] = hp;
-        }
+        int h0, h1;
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
         s16x2 l0 = {0, 0}, l1 = {0, 0};
-        l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
-        l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
-        l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
-        l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
-        int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][0], xr[i][1], 0, false);
-        h0 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][2], xr[i][3], h0, true);
-        int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][4], xr[i][5], 0, false);
-        h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][6], xr[i][7], h1, true);
+        if (XPACKED) {   // the record already holds the three payloads
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hi[k] = __builtin_bit_cast(int, xr[i][k]);
+          l0 = __builtin_bit_cast(s16x2, xr[i][4]);
+          l1 = __builtin_bit_cast(s16x2, xr[i][5]);
+          h0 = __builtin_bit_cast(int, xr[i][6]);
+          h1 = __builtin_bit_cast(int, xr[i][7]);
+        } else {
+          float lo[8];
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            int hp;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(xr[i][j]), "v"(xr[i][j + 1]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hp), "v"(xr[i][j]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hp), "v"(xr[i][j + 1]));
+            hi[j >> 1] = hp;
+          }
+          l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+          l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+          l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+          l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+          h0 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][0], xr[i][1], 0, false);
+          h0 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][2], xr[i][3], h0, true);
+          h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][4], xr[i][5], 0, false);
+          h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][6], xr[i][7], h1, true);
+        }
         const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
         *reinterpret_cast<i32x4*>(base + off) = hi;
         const int off8 = OFF_X8 + (oct >> 2) * (NXP * 32) + pix * 32 + (oct & 3) * 8;
@@ -1272,7 +1337,7 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
 // (eovae_absmax_bits) when x may sit outside f16's range (gradients), else NULL.
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual, float* y,
                             const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
-                            int Wout, int mode, int subpix, void* stream) {
+                            int Wout, int mode, int subpix, int xpacked, void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_f16c8_fwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_f16c8_fwd: bad shape");
   EOVAE_CHECK_ARG(mode == MODE_NORMAL, "conv3x3_f16c8_fwd: mode %d unsupported (stride-1 'normal' layers and the "
@@ -1280,7 +1345,8 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 4, "conv3x3_f16c8_fwd: subpix %d", subpix);
   ConvCArgs a;
   a.x = x; a.wp = (const unsigned char*)wp; a.bias = bias; a.res = residual; a.y = y; a.xamax = xamax;
-  a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
+  a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1; a.packed = xpacked;
+  EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && !xamax), "conv3x3_f16c8_fwd: packed input is a forward, plain 3x3 input");
   if (subpix == 0) {
     const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;
     EOVAE_CHECK_ARG(Hout == eh && Wout == ew, "conv3x3_f16c8_fwd: output %dx%d does not match mode %d", Hout,
@@ -1337,11 +1403,14 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(512);
 #define EOVAE_LAUNCH_C8(TH)                                                                                   \
   switch (subpix) {                                                                                           \
-    case 0: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0>), grid, blk, 0, st, a); break;                    \
-    case 1: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 1>), grid, blk, 0, st, a); break;                    \
-    case 2: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 2>), grid, blk, 0, st, a); break;                    \
-    case 3: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 3>), grid, blk, 0, st, a); break;                    \
-    default: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 4>), grid, blk, 0, st, a); break;                   \
+    case 0:                                                                                                   \
+      if (xpacked) hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0, true>), grid, blk, 0, st, a);                \
+      else hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0, false>), grid, blk, 0, st, a);                       \
+      break;                                                                                                  \
+    case 1: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 1, false>), grid, blk, 0, st, a); break;             \
+    case 2: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 2, false>), grid, blk, 0, st, a); break;             \
+    case 3: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 3, false>), grid, blk, 0, st, a); break;             \
+    default: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 4, false>), grid, blk, 0, st, a); break;            \
   }
   EOVAE_LAUNCH_C8(8)
 #undef EOVAE_LAUNCH_C8
@@ -1353,11 +1422,13 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
 // (device pointer to the float bits of max|dy|, eovae_absmax_bits / eovae_gn_silu_bwd; NULL = unscaled dy)
 int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db, const unsigned* dyamax, int N,
                               int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
-                              void* stream) {
+                              int xpacked, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_f16c8_wgrad: null pointer");
   EOVAE_CHECK_ARG(!(db && subpix == 1), "conv3x3_f16c8_wgrad: db is not produced in subpix 1");
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_f16c8_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_f16c8_wgrad: mode %d unsupported", mode);
+  EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && mode == MODE_NORMAL && Cin % 64 == 0),
+                  "conv3x3_f16c8_wgrad: packed x needs a plain layer with Cin %% 64 == 0");
   WgCArgs a;
   a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
@@ -1384,9 +1455,10 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
   a.xcd_remap = (a.ncib * ncob > 1 && split % 8 == 0) ? 1 : 0;
   dim3 grid(a.ncib * ncob * split);
   hipStream_t st = (hipStream_t)stream;
-  if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1>), grid, dim3(512), 0, st, a);
-  else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0>), grid, dim3(512), 0, st, a);
+  if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1, false>), grid, dim3(512), 0, st, a);
+  else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2, false>), grid, dim3(512), 0, st, a);
+  else if (xpacked) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, true>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, false>), grid, dim3(512), 0, st, a);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad");
   return EOVAE_OK;
 }

@@ -99,6 +99,63 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// stage 3, f16c8 operand form: normalise + affine + silu and write the result as the OPERAND RECORDS the f16c8
+// convolution kernels multiply with (conv_f16c8.hip), instead of fp32:
+//   pa[n][C/8][HW] x 32 B = { 8 x f16 y | 8 x e5m2 (y - f16(y)) * 2^12 | 8 x e5m2 y }      (channels 8g .. 8g+7)
+// Same 4 B per element as the fp32 tensor it replaces.  The consumers (3x3 forward convolution, weight gradient)
+// then copy records into LDS with no conversion work -- the conversion is done ONCE here, in a kernel that is
+// HBM-bound anyway, instead of once per 128-co block of the forward and once per block of the weight gradient.
+// One thread = one pixel x 8 channels; grid = N * C/8 * ceil(HW / 256).
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_packed_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ stats,
+                                                              int* __restrict__ pa, int C, int HW, int cpg,
+                                                              int pblocks) {
+  typedef int i32x4v __attribute__((ext_vector_type(4)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const int pb = blockIdx.x % pblocks, og = blockIdx.x / pblocks;   // og = n * C/8 + octet
+  const int oct = og % (C / 8), n = og / (C / 8);
+  const int p = pb * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = oct * 8 + j;
+    const int ng = n * (C / cpg) + c / cpg;
+    const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
+    const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+    float o = x[((size_t)n * C + c) * HW + p] * sc + sh;
+    v[j] = SILU ? silu_f(o) : o;
+  }
+  int pk[4];
+  float lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    int hh;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v[j]), "v"(v[j + 1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hh), "v"(v[j]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hh), "v"(v[j + 1]));
+    pk[j >> 1] = hh;
+  }
+  s16x2 l0 = {0, 0}, l1 = {0, 0};
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+  int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+  h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
+  int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
+  h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h1, true);
+  i32x4v a0, a1;
+  a0[0] = pk[0]; a0[1] = pk[1]; a0[2] = pk[2]; a0[3] = pk[3];
+  a1[0] = __builtin_bit_cast(int, l0); a1[1] = __builtin_bit_cast(int, l1); a1[2] = h0; a1[3] = h1;
+  i32x4v* rec = reinterpret_cast<i32x4v*>(pa + ((size_t)og * HW + p) * 8);
+  rec[0] = a0;
+  rec[1] = a1;
+}
+
 // backward pass 1: per (n,c) plane  s1 = sum dz, s2 = sum dz * xhat   (dz = dy * silu'(z))
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x,
@@ -302,6 +359,31 @@ int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, flo
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(N * C * chunks), dim3(256), 0, st, x, gamma,
                        beta, stats, y, C, HW, cpg, chunks);
   EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd");
+  return EOVAE_OK;
+}
+
+// As eovae_gn_silu_fwd, but the output is written as f16c8 operand records (see gn_apply_packed_kernel):
+// pa has N*C*HW dwords (the size of the fp32 output it replaces); C must be a multiple of 8.
+int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
+                             int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream) {
+  EOVAE_CHECK_ARG(x && gamma && beta && pa && stats && ws, "gn_silu_fwd_packed: null pointer");
+  EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C % 8 == 0, "gn_silu_fwd_packed: C=%d G=%d", C, G);
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = C / G;
+  const size_t gsize = (size_t)cpg * HW;
+  const int ns = nsplit_for(gsize);
+  double* part = (double*)ws;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats,
+                     N * G, ns, 1.0 / (double)gsize, eps);
+  const int pblocks = cdiv(HW, 256);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_packed_kernel<true>, dim3(N * (C / 8) * pblocks), dim3(256), 0, st, x, gamma, beta,
+                       stats, (int*)pa, C, HW, cpg, pblocks);
+  else
+    hipLaunchKernelGGL(gn_apply_packed_kernel<false>, dim3(N * (C / 8) * pblocks), dim3(256), 0, st, x, gamma,
+                       beta, stats, (int*)pa, C, HW, cpg, pblocks);
+  EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed");
   return EOVAE_OK;
 }
 

@@ -32,12 +32,14 @@ class GroupNorm(nn.GroupNorm):
         super().__init__(num_groups=groups, num_channels=channels, eps=1e-6, affine=True)
         self.silu = silu
 
-    def forward(self, x):
-        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, self.silu)
+    def forward(self, x, packed=False):
+        """packed=True: the caller feeds the result to a plain 3x3 Conv2d and nothing else; in f16c8 mode it is then
+        produced as that kernel's operand records instead of fp32 (ops.mark_packed)."""
+        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, self.silu, packed)
 
-    def forward_fork(self, x):
+    def forward_fork(self, x, packed=False):
         """-> (normalised+activated x, x for the residual branch); see ops.GroupNormSiluForkFn."""
-        return ops.group_norm_silu_fork(x, self.weight, self.bias, self.num_groups, self.eps, self.silu)
+        return ops.group_norm_silu_fork(x, self.weight, self.bias, self.num_groups, self.eps, self.silu, packed)
 
 
 class Downsample(nn.Module):  # layers.py:25-37
@@ -76,10 +78,10 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x, emb=None):
-        a, xs = self.norm1.forward_fork(x)
-        h = self.conv1(a)
+        a, xs = self.norm1.forward_fork(x, packed=True)        # conv1 / conv2 are the only consumers of the
+        h = self.conv1(a)                                      # two GroupNorm outputs: operand records
         skip = self.nin_shortcut(xs) if self.in_channels != self.out_channels else xs
-        return self.conv2(self.norm2(h), residual=skip)
+        return self.conv2(self.norm2(h, packed=True), residual=skip)
 
 
 class AttnBlock(nn.Module):

@@ -30,8 +30,9 @@ SIGNATURES = {
     'eovae_absmax_bits': (_i, [_p, _sz, _p, _p]),
     'eovae_conv3x3_f16c8_packed_bytes': (_sz, [_i, _i, _i]),
     'eovae_conv3x3_f16c8_pack': (_i, [_p, _p, _i, _i, _i, _f, _p]),
-    'eovae_conv3x3_f16c8_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_conv3x3_f16c8_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_gn_silu_fwd_packed': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_subpix_expand': (_i, [_p, _p, _i, _i, _p]),
     'eovae_down_expand': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_down_fold': (_i, [_p, _p, _i, _i, _p]),
@@ -81,7 +82,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 5  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

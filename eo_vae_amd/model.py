@@ -66,7 +66,7 @@ class Encoder(nn.Module):
             if level != self.num_resolutions - 1:
                 h = stage.downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        return self.quant_conv(self.conv_out(self.norm_out(h)))
+        return self.quant_conv(self.conv_out(self.norm_out(h, packed=True)))
 
 
 class Decoder(nn.Module):
@@ -116,7 +116,7 @@ class Decoder(nn.Module):
                 h = block(h)
             if level != 0:
                 h = self.up[level].upsample(h)
-        h = self.norm_out(h)
+        h = self.norm_out(h, packed=True)     # consumed by conv_out only (plain or dynamic 3x3)
         if self.use_dynamic_ops:
             assert wvs is not None, 'wvs must be provided for Dynamic Decoder'
             return self.conv_out(h, wvs)

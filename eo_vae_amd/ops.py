@@ -163,6 +163,27 @@ def _tag_amax(t, amax):
         t._eovae_amax = (amax, t._version)
 
 
+# GroupNorm + SiLU can hand its result to the next 3x3 convolution as f16c8 OPERAND RECORDS instead of fp32
+# (csrc/groupnorm.hip gn_apply_packed_kernel): a float32 tensor of the usual [N, C, H, W] shape whose BYTES are the
+# records (N*C*H*W dwords either way).  It is only meaningful to Conv2dFn (plain 3x3, f16c8), which recognises it by
+# this tag; any other consumer raises.
+def mark_packed(t):
+    t._eovae_packed = t._version
+    return t
+
+
+def is_packed(t):
+    return getattr(t, '_eovae_packed', None) == t._version
+
+
+def packed_ok(channels):
+    """Can a GroupNorm output with this many channels be handed over as operand records?"""
+    return CONV_PRECISION == 'f16c8' and channels % 64 == 0 and PACKED_ACTIVATIONS
+
+
+PACKED_ACTIVATIONS = os.environ.get('EOVAE_PACKED_ACT', '1') != '0'
+
+
 def amax_of(t):
     """absmax bits of t: the producer's tag when it is still valid, else one reduction pass."""
     tag = getattr(t, '_eovae_amax', None)
@@ -187,32 +208,37 @@ def _pack3x3(w4, rows, cols, flip, f16c8):
     return wp
 
 
-def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None):
+def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None,
+               packed=False):
     lib = L.load()
+    if packed and not f16c8:
+        raise L.EovaeError('conv2d: operand-record input reached a non-f16c8 kernel')
     if f16c8:
         L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
                                             L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
-                                            L.stream()), 'eovae_conv3x3_f16c8_fwd')
+                                            int(packed), L.stream()), 'eovae_conv3x3_f16c8_fwd')
     else:
         L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
                                            cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], subpix,
                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
 
 
-def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix):
+def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False):
     """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16."""
     lib = L.load()
     if CONV_PRECISION == 'f16c8':
         L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax_of(dy)), n,
-                                              cin, h, w, cout, ho, wo, mode, subpix, L.stream()),
+                                              cin, h, w, cout, ho, wo, mode, subpix, int(packed), L.stream()),
                 'eovae_conv3x3_f16c8_wgrad')
+    elif packed:
+        raise L.EovaeError('conv2d backward: operand-record input reached a non-f16c8 kernel')
     else:
         L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w, cout, ho,
                                              wo, mode, _PREC[CONV_PRECISION], subpix, L.stream()),
                 'eovae_conv3x3_bf16_wgrad')
 
 
-def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None):
+def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=False):
     """3x3 stride-1 conv / data-gradient on the 16-bit matrix cores (weight in PyTorch layout).
     amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode."""
     cout, cin = weight.shape[0], weight.shape[1]
@@ -229,7 +255,10 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None):
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout_gemm * cin_g * 9,
                                          4.0 * (x.numel() + y.numel() + weight.numel()))
         ev0.record()
-    _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, amax if flip else None)
+    if packed and not f8:
+        raise L.EovaeError('conv2d: operand-record input needs the f16c8 kernel (K % 32 == 0, mode normal)')
+    _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, amax if flip else None,
+               packed)
     if timed:
         ev1.record()
     return y
@@ -400,12 +429,17 @@ class Conv2dFn(torch.autograd.Function):
             raise L.EovaeError(f'conv2d: input has {x.shape[1]} channels, weight expects {cin}')
         res = _c(residual) if residual is not None else None
         bias_c = _c(bias) if bias is not None else None
+        packed = is_packed(x)
+        if packed and not (ks == 3 and m == MODE_NORMAL and CONV_PRECISION == 'f16c8'):
+            raise L.EovaeError('conv2d: operand-record input (GroupNorm packed output) is only understood by the '
+                               "plain 3x3 f16c8 convolution")
+        ctx.packed = packed
         if ks == 3 and m == MODE_UP and res is None and _subpix_ok(weight):
             y = up_conv_subpix(x, weight, bias_c)
         elif ks == 3 and m == MODE_DOWN and res is None and _down_ok(x, weight):
             y = down_conv_s2d(x, weight, bias_c)
         elif ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
-            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False)
+            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed)
         elif ks == 1 and CONV_PRECISION != 'f32':
             y = conv1x1_lowp(x, weight, bias_c, res)
         else:
@@ -477,7 +511,8 @@ class Conv2dFn(torch.autograd.Function):
             if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
                 if want_db:  # bias gradient rides on the dy tiles the wgrad kernel stages anyway
                     db = torch.zeros(cout, dtype=torch.float32, device=x.device)
-                _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, dy.shape[2], dy.shape[3], m, 0)
+                _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, dy.shape[2], dy.shape[3], m, 0,
+                                 packed=ctx.packed)
             else:
                 L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
                                                dy.shape[2], dy.shape[3], ks, m, L.stream()),
@@ -502,19 +537,26 @@ def conv2d(x, weight, bias=None, residual=None, mode='normal'):
 # ------------------------------------------------------------------------------------------
 
 
+def _gn_forward(x, gamma, beta, groups, eps, silu, packed):
+    n, c, h, w = x.shape
+    lib = L.load()
+    ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, groups), x.device)
+    y = torch.empty_like(x)
+    stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
+    fn = lib.eovae_gn_silu_fwd_packed if packed else lib.eovae_gn_silu_fwd
+    L.check(fn(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), n, c, h * w, groups, eps, int(silu),
+               L.ptr(ws), L.stream()), 'eovae_gn_silu_fwd')
+    return y, stats
+
+
 class GroupNormSiluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, packed=False):
         L.require_gpu(x, 'group_norm')
         x, gamma, beta = _c(x), _c(gamma), _c(beta)
         n, c, h, w = x.shape
         lib = L.load()
-        ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, groups), x.device)
-        y = torch.empty_like(x)
-        stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
-        L.check(lib.eovae_gn_silu_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats),
-                                      n, c, h * w, groups, eps, int(silu), L.ptr(ws), L.stream()),
-                'eovae_gn_silu_fwd')
+        y, stats = _gn_forward(x, gamma, beta, groups, eps, silu, packed)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
         return y
@@ -534,11 +576,15 @@ class GroupNormSiluFn(torch.autograd.Function):
                                       ctx.groups, int(ctx.silu), L.ptr(ws), L.stream()),
                 'eovae_gn_silu_bwd')
         _tag_amax(dx, amax)
-        return dx, dgamma, dbeta, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None
 
 
-def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True):
-    return GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu)
+def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
+    """packed=True: the result is handed over as f16c8 operand records (see mark_packed) -- only for a
+    consumer that is a plain 3x3 Conv2dFn in f16c8 mode."""
+    packed = bool(packed and silu and packed_ok(x.shape[1]))
+    y = GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu, packed)
+    return mark_packed(y) if packed else y
 
 
 class GroupNormSiluForkFn(torch.autograd.Function):
@@ -547,17 +593,10 @@ class GroupNormSiluForkFn(torch.autograd.Function):
     instead of a separate elementwise-add pass over the activation."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, packed=False):
         L.require_gpu(x, 'group_norm')
         x, gamma, beta = _c(x), _c(gamma), _c(beta)
-        n, c, h, w = x.shape
-        lib = L.load()
-        ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, groups), x.device)
-        y = torch.empty_like(x)
-        stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
-        L.check(lib.eovae_gn_silu_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats),
-                                      n, c, h * w, groups, eps, int(silu), L.ptr(ws), L.stream()),
-                'eovae_gn_silu_fwd')
+        y, stats = _gn_forward(x, gamma, beta, groups, eps, silu, packed)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
         return y, x.view_as(x)
@@ -578,11 +617,13 @@ class GroupNormSiluForkFn(torch.autograd.Function):
                                       h * w, ctx.groups, int(ctx.silu), L.ptr(ws), L.stream()),
                 'eovae_gn_silu_bwd')
         _tag_amax(dx, amax)
-        return dx, dgamma, dbeta, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None
 
 
-def group_norm_silu_fork(x, gamma, beta, groups=32, eps=1e-6, silu=True):
-    return GroupNormSiluForkFn.apply(x, gamma, beta, groups, eps, silu)
+def group_norm_silu_fork(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
+    packed = bool(packed and silu and packed_ok(x.shape[1]))
+    y, skip = GroupNormSiluForkFn.apply(x, gamma, beta, groups, eps, silu, packed)
+    return (mark_packed(y) if packed else y), skip
 
 
 # ------------------------------------------------------------------------------------------

@@ -80,13 +80,22 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
                              void* stream);
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
-                            int Hout, int Wout, int mode, int subpix, void* stream);
+                            int Hout, int Wout, int mode, int subpix, int xpacked, void* stream);
 /* f16c8 weight gradient (same tiling and sub-pixel forms as eovae_conv3x3_bf16_wgrad; replaces the same
  * autograd call site of F.conv2d, layers.py:29-50, 70-110): per 32 pixels and tap 2 f16 MFMAs + 1 block-scaled
  * fp8 MFMA [dy_lo|dy_hi].[x_hi|x_lo].  dyamax as for the data gradient (NULL = dy used unscaled). */
 int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db,
                               const unsigned* dyamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
-                              int Wout, int mode, int subpix, void* stream);
+                              int Wout, int mode, int subpix, int xpacked, void* stream);
+/* xpacked = 1 (both entries above): x is not fp32 NCHW but the f16c8 OPERAND-RECORD tensor written by
+ * eovae_gn_silu_fwd_packed: [N][C/8][H][W] records of 32 bytes = { 8 x f16 y | 8 x e5m2 (y - f16(y)) * 2^12 |
+ * 8 x e5m2 y } for channels 8g..8g+7 -- N*C*H*W dwords, the size of the fp32 activation it replaces.  The
+ * conversion to the kernels' operand format is then done once (in the HBM-bound GroupNorm-apply pass) instead of
+ * once per 128-co block of the forward convolution and once per block of the weight gradient.  Forward / weight
+ * gradient of plain 3x3 layers only (subpix 0, mode 0; wgrad: Cin %% 64 == 0).  Replaces the
+ * `h = conv(swish(norm(h)))` pairs of layers.py:91-111 and model.py:193-196, 349-357. */
+int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
+                             int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream);
 /* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);

@@ -161,3 +161,40 @@ def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol, gscale=1.0):
     assert rel_err(xg.grad, xr.grad) < tol
     assert rel_err(wg.grad, wr.grad) < max(tol, 2e-5)
     assert rel_err(bg.grad, br.grad) < 2e-5      # fp32 sums of dy (fused into the wgrad kernel)
+
+
+@pytest.mark.parametrize('n,c,cout,h,w', [(2, 64, 96, 24, 40), (1, 128, 128, 64, 64), (2, 256, 128, 17, 35)])
+def test_groupnorm_operand_records_equal_the_fp32_hand_over(n, c, cout, h, w):
+    """f16c8: GroupNorm+SiLU handing its result to the 3x3 convolution as operand records (converted once, in the
+    GroupNorm-apply pass) must give what the fp32 hand-over gives: the forward bit for bit (the same conversion
+    instructions run in either place), the gradients up to the weight gradient's atomic ordering."""
+    from eo_vae_amd import ops
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 'f16c8'
+    try:
+        x = hashed((n, c, h, w), 11, 1.0)
+        gam, bet = 1.0 + hashed((c,), 12, 0.2), hashed((c,), 13, 0.2)
+        wt, b = hashed((cout, c, 3, 3), 14, 1.0 / (c * 9) ** 0.5), hashed((cout,), 15, 0.1)
+        gy = hashed((n, cout, h, w), 16, 1.0)
+        outs = []
+        for packed in (False, True):
+            xg, gg, bg, wg, cb = [t.cuda().requires_grad_(True) for t in (x, gam, bet, wt, b)]
+            a = ops.group_norm_silu(xg, gg, bg, 32, 1e-6, True, packed)
+            assert ops.is_packed(a) == packed
+            y = ops.conv2d(a, wg, cb, None, 'normal')
+            y.backward(gy.cuda())
+            torch.cuda.synchronize()
+            outs.append((y.detach().cpu(), xg.grad.cpu(), wg.grad.cpu(), gg.grad.cpu(), cb.grad.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0])                       # forward: identical bits
+        for k in (1, 2, 3, 4):
+            assert rel_err(outs[1][k], outs[0][k]) < 2e-6, k
+        # and against plain fp32 torch
+        xr, gr, br, wr, cr = [t.clone().requires_grad_(True) for t in (x, gam, bet, wt, b)]
+        ref = torch.nn.functional.conv2d(torch.nn.functional.silu(torch.nn.functional.group_norm(xr, 32, gr, br, 1e-6)), wr, cr, padding=1)
+        ref.backward(gy)
+        assert rel_err(outs[1][0], ref) < 1e-4 and rel_err(outs[1][2], wr.grad) < 1e-4 and rel_err(outs[1][1], xr.grad) < 2e-4
+        with pytest.raises(ops.L.EovaeError):     # a consumer that does not understand the records must refuse them
+            ops.conv2d(ops.group_norm_silu(x.cuda(), gam.cuda(), bet.cuda(), 32, 1e-6, True, True),
+                       hashed((cout, c, 1, 1), 17, 0.1).cuda(), None, None, 'normal')
+    finally:
+        ops.CONV_PRECISION = old
