@@ -1233,8 +1233,10 @@ __global__ void absmax_bits_kernel(const float* __restrict__ x, size_t n, unsign
 // flip = 0: k = ci, m = co;  flip = 1 (data gradient): k = co, m = ci, taps reversed.
 // One thread = 4 consecutive k of one (tile, m): one dword of each fp8 image, 8 bytes of the f16 image.
 __global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp, int Cout, int Cin,
-                                  int nchunk, int ncob, int flip, float scale, const unsigned* __restrict__ hdr) {
+                                  int nchunk, int ncob, int flip, float scale, const unsigned* __restrict__ hdr,
+                                  unsigned* __restrict__ hdr_copy) {
   const unsigned wbits = *hdr;   // amax(|w|) bits of the UNSCALED weights; `scale` is a power of two
+  if (hdr_copy && blockIdx.x == 0 && threadIdx.x == 0) *hdr_copy = wbits;   // second orientation: own header
   const float amax = __builtin_bit_cast(float, wbits) * fabsf(scale);
   const int e1 = amax > 0.f ? 7 - expo_of_bits(__builtin_bit_cast(unsigned, amax)) : 0;
   const float s_hi = pow2f(e1), s_lo = pow2f(e1 + 12);   // |wl| <= 2^-11 |w|: wl * s_lo stays under 256
@@ -1327,8 +1329,42 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
-                     scale, (const unsigned*)hdr);
+                     scale, (const unsigned*)hdr, (unsigned*)nullptr);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack");
+  return EOVAE_OK;
+}
+
+// Both orientations of one layer in one call: wp_fwd (flip 0) for the forward convolution and wp_bwd (flip 1) for its
+// data gradient, from ONE amax pass (4 launches instead of 6 for a layer that is multiplied forward and backward
+// in the same step).  Buffer sizes: eovae_conv3x3_f16c8_packed_bytes(Cout, Cin, 0 / 1).
+int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, int Cout, int Cin, float scale,
+                                  void* stream) {
+  EOVAE_CHECK_ARG(w && wp_fwd && wp_bwd && Cout > 0 && Cin > 0, "conv3x3_f16c8_pack_pair: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* b0 = (unsigned char*)wp_fwd;
+  unsigned char* b1 = (unsigned char*)wp_bwd;
+  const int nch0 = cdiv(Cin, 32), ncb0 = cdiv(Cout, 128), nch1 = cdiv(Cout, 32), ncb1 = cdiv(Cin, 128);
+  unsigned* hdr0 = (unsigned*)(b0 + (size_t)9 * nch0 * ncb0 * 16384);
+  unsigned* hdr1 = (unsigned*)(b1 + (size_t)9 * nch1 * ncb1 * 16384);
+  if (hipMemsetAsync(hdr0, 0, 16, st) != hipSuccess) {
+    eovae_set_error("conv3x3_f16c8_pack_pair: memset failed");
+    return EOVAE_ERR_LAUNCH;
+  }
+  const size_t nw = (size_t)Cout * Cin * 9;
+  size_t ab = (nw / 4 + 255) / 256;
+  if (ab > 1024) ab = 1024;
+  if (ab < 1) ab = 1;
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)ab), dim3(256), 0, st, w, nw, hdr0);
+  auto launch = [&](unsigned char* base, int nchunk, int ncob, int flip, unsigned* copy) {
+    const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
+                       scale, (const unsigned*)hdr0, copy);
+  };
+  launch(b0, nch0, ncb0, 0, nullptr);
+  launch(b1, nch1, ncb1, 1, hdr1);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack_pair");
   return EOVAE_OK;
 }
 

@@ -238,15 +238,27 @@ def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, p
                 'eovae_conv3x3_bf16_wgrad')
 
 
-def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=False):
+def pack_pair_f16c8(weight):
+    """(forward, data-gradient) f16c8 weight packs of one plain 3x3 layer from ONE amax pass."""
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    wp0 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device=weight.device)
+    wp1 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 1), dtype=torch.uint8, device=weight.device)
+    L.check(lib.eovae_conv3x3_f16c8_pack_pair(L.ptr(weight), L.ptr(wp0), L.ptr(wp1), cout, cin, 1.0, L.stream()),
+            'eovae_conv3x3_f16c8_pack_pair')
+    return wp0, wp1
+
+
+def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=False, wp=None):
     """3x3 stride-1 conv / data-gradient on the 16-bit matrix cores (weight in PyTorch layout).
-    amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode."""
+    amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode.  wp: an already packed weight."""
     cout, cin = weight.shape[0], weight.shape[1]
     n, cin_g, h, w = x.shape
     f8 = _use_f16c8(cin_g) and mode == MODE_NORMAL
     if f8 and flip and amax is None:
         amax = amax_of(x)
-    wp = _pack3x3(weight, cout, cin, flip, f8)
+    if wp is None:
+        wp = _pack3x3(weight, cout, cin, flip, f8)
     ho, wo = _out_hw(h, w, mode)
     y = torch.empty(n, cout_gemm, ho, wo, dtype=torch.float32, device=x.device)
     timed = CONV3X3_TIMER is not None
@@ -439,7 +451,12 @@ class Conv2dFn(torch.autograd.Function):
         elif ks == 3 and m == MODE_DOWN and res is None and _down_ok(x, weight):
             y = down_conv_s2d(x, weight, bias_c)
         elif ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
-            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed)
+            wp = None
+            ctx.wp_bwd = None
+            # both weight orientations from one amax pass when the data gradient of this layer will be asked for
+            if m == MODE_NORMAL and _use_f16c8(cin) and _use_f16c8(cout) and ctx.needs_input_grad[0]:
+                wp, ctx.wp_bwd = pack_pair_f16c8(weight)
+            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed, wp=wp)
         elif ks == 1 and CONV_PRECISION != 'f32':
             y = conv1x1_lowp(x, weight, bias_c, res)
         else:
@@ -473,7 +490,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = down_conv_s2d_dgrad(dy, weight, h, w)
         elif ctx.needs_input_grad[0] and ks == 3 and CONV_PRECISION != 'f32':
             if m == MODE_NORMAL:
-                dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_NORMAL, True)
+                dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_NORMAL, True, wp=getattr(ctx, 'wp_bwd', None))
             elif m == MODE_DOWN:
                 dx = conv3x3_lowp(dy, weight, None, None, cin, MODE_ZINS, True)
                 if dx.shape[2] != h or dx.shape[3] != w:

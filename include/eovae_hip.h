@@ -78,6 +78,9 @@ int eovae_absmax_bits(const float* x, size_t n, unsigned* out_bits, void* stream
 size_t eovae_conv3x3_f16c8_packed_bytes(int Cout, int Cin, int flip);
 int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale,
                              void* stream);
+/* both orientations (flip 0 into wp_fwd, flip 1 into wp_bwd) from one amax pass */
+int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, int Cout, int Cin, float scale,
+                                  void* stream);
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, void* stream);
