@@ -491,6 +491,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     }
     auto body = [&](auto full_t) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_t)::value;
+      // residual of the whole wave tile requested up front (2 x 4 x 4 x NI loads in flight, one wait): fetched
+      // batch by batch, each of the eight batches exposed a full memory latency in front of its stores
+      float rv[2][4][4][NI];
+      if (rn) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int co = co_base + i * 32 + k + 8 * qq;
+              const int cc = (FULL || co < chans) ? co : chans - 1;
+#pragma unroll
+              for (int j = 0; j < NI; ++j) rv[i][qq][k][j] = rn[(size_t)cc * out_plane + rowoff[j]];
+            }
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
               for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(acc[i][j][4 * qq + k]));
             continue;
           }
-          float bias4[4], rv[4][NI];
+          float bias4[4];
           int coc[4];
           bool cok[4];
 #pragma unroll
@@ -512,19 +528,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
             coc[k] = cok[k] ? co : chans - 1;
             bias4[k] = a.bias ? a.bias[coc[k]] : 0.f;
           }
-          if (rn) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-              for (int j = 0; j < NI; ++j) rv[k][j] = rn[(size_t)coc[k] * out_plane + rowoff[j]];
-          }
           float v[4][NI];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
               v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k];
-              if (rn) v[k][j] += rv[k][j];
+              if (rn) v[k][j] += rv[i][qq][k][j];
               if (!FULL) asm volatile("" : "+v"(v[k][j]));
             }
 #pragma unroll

@@ -23,6 +23,7 @@ for cin, cout, hw in shapes:
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
     dy = torch.randn(B, cout, hw, hw, device='cuda')
     y = torch.empty_like(dy)
+    res = torch.randn_like(dy) if os.environ.get('LB_RES') == '1' else None   # conv2 of a ResnetBlock adds its skip
     flops = 2.0 * B * hw * hw * cin * cout * 9
     fns = {}
     for prec in precs:
@@ -31,8 +32,8 @@ for cin, cout, hw in shapes:
             L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
             dwp8 = torch.zeros(9 * cout * cin, device='cuda')
             amax = ops.absmax_bits(dy)
-            fns[prec] = (lambda wp=wp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, L.stream()),
-                         lambda dwp8=dwp8, amax=amax: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp8), None, L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, L.stream()))
+            fns[prec] = (lambda wp=wp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.stream()),
+                         lambda dwp8=dwp8, amax=amax: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp8), None, L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.stream()))
         else:
             p = ops._PREC[prec]
             wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(cout, cin, 0), dtype=torch.bfloat16, device='cuda')
