@@ -14,6 +14,6 @@ void eovae_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* eovae_last_error(void) { return g_err; }
-int eovae_abi_version(void) { return 5; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked)
+int eovae_abi_version(void) { return 6; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

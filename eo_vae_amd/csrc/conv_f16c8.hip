@@ -56,8 +56,15 @@ struct ConvCArgs {
   int xcd_remap;
   int ntiles;                // tiles x co-blocks walked by the persistent grid
   int packed;                // x = f16c8 operand records (GroupNorm-apply, forward only)
+  double* gn_sums;           // [N][gn_groups][2] += (sum, sum of squares) of the OUTPUT per (image, channel group), or null
+  int gn_groups, gn_shift;   // channel groups of the GroupNorm that reads y; log2(channels per group)
 };
 
+// x of the lane whose index within its quad is permuted by CTRL (0xB1: lane ^ 1, 0x4E: lane ^ 2)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 // power of two 2^k as a float, k clamped to the normal range
 __device__ __forceinline__ float pow2f(int k) {
   k = k < -126 ? -126 : (k > 127 ? 127 : k);
@@ -107,6 +114,9 @@ __device__ unsigned long long c8_stamps[C8_NBLK * 8 * C8_MAXREC * C8_NPT];
 #else
 #define C8_STAMP(id) do {} while (0)
 #endif
+#ifndef EOVAE_C8_GNABL
+#define EOVAE_C8_GNABL 0
+#endif
 #ifndef EOVAE_C8_ABL
 #define EOVAE_C8_ABL 0   // timing-only experiments: 1 few stores, 2 no halo loads, 4 no conversion, 8 no weight DMA, 16 no MFMAs
 #endif
@@ -131,7 +141,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   constexpr int LPG = XPT;                      // loads per group
   constexpr bool KGATHER = SUBPIX == 2 || SUBPIX == 3;  // K channels gathered at a parity
   constexpr bool MSHUFFLE = SUBPIX == 1 || SUBPIX == 4; // M rows pixel-shuffled on store
-  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_W + 4 * WTAP];
+  constexpr int GNS = NW * 2 * 8 * 16 * 4;      // GroupNorm partials of the tile being stored: [wave][sum|sumsq][batch][lane quad]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_W + 4 * WTAP + GNS];
+  static_assert(OFF_W + 4 * WTAP + GNS <= 160 * 1024, "LDS");
 
   const int tid = threadIdx.x;
   // readfirstlane: the wave index is uniform, which lets the role branches below be scalar branches
@@ -467,6 +479,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
                                                                     1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
   };
 
+  // GroupNorm partial sums of a stored tile (a.gn_sums): gslot[wave][sum|sumsq][batch (i, qq)][quad of lanes] is
+  // written by the epilogue (each wave its own cells, so plain stores); after the next workgroup barrier
+  // gn_flush() folds the 4 row waves x 8 quads behind each (channel quartet, value) and adds the result to
+  // gn_sums[n][group] in double.  Every cell is rewritten by the next epilogue, several barriers later.
+  float* const gslot = reinterpret_cast<float*>(smem + OFF_W + 4 * WTAP);
+  auto gn_flush = [&](int tn, int tcob) __attribute__((always_inline)) {
+    const int out = tid >> 3, sub = tid & 7;
+    const int v = out >> 5, wc = (out >> 4) & 1, b = (out >> 1) & 7, hh = out & 1;
+    const int w = (sub >> 1) * 2 + wc;
+    const float4 c4 = *reinterpret_cast<const float4*>(gslot + ((w * 2 + v) * 8 + b) * 16 + hh * 8 + (sub & 1) * 4);
+    float t = (c4.x + c4.y) + (c4.z + c4.w);
+    t += dpp_quad<0xB1>(t);
+    t += dpp_quad<0x4E>(t);
+    t += __shfl_xor(t, 4, 8);
+    const int co = tcob * BM + wc * 64 + (b >> 2) * 32 + (b & 3) * 8 + 4 * hh;
+    if (sub == 0 && co < a.Cout)
+      atomicAdd(a.gn_sums + ((size_t)tn * a.gn_groups + (co >> a.gn_shift)) * 2 + v, (double)t);
+  };
+
   // Epilogue of one tile: as conv_bf16x3.hip (batched unconditional bias / residual loads, plain stores on
   // full tiles), plus the exact power-of-two un-scaling of a scaled input.
   auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
@@ -491,12 +522,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     }
     auto body = [&](auto full_t) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_t)::value;
-      // residual of the whole wave tile requested up front (2 x 4 x 4 x NI loads in flight, one wait): fetched
-      // batch by batch, each of the eight batches exposed a full memory latency in front of its stores
-      float rv[2][4][4][NI];
-      if (rn) {
+      // residual requested half a wave tile at a time (4 x 4 x NI loads in flight, one wait): fetched batch by
+      // batch, each of the eight batches exposed a full memory latency in front of its stores
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        float rv[4][4][NI];
+        if (rn) {
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
@@ -504,11 +535,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
               const int co = co_base + i * 32 + k + 8 * qq;
               const int cc = (FULL || co < chans) ? co : chans - 1;
 #pragma unroll
-              for (int j = 0; j < NI; ++j) rv[i][qq][k][j] = rn[(size_t)cc * out_plane + rowoff[j]];
+              for (int j = 0; j < NI; ++j) rv[qq][k][j] = rn[(size_t)cc * out_plane + rowoff[j]];
             }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
+        }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           if ((EOVAE_C8_ABL & 1) && (i || qq)) {   // timing-only: keep the values alive, store 1/8 of them
@@ -534,9 +563,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
               v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k];
-              if (rn) v[k][j] += rv[i][qq][k][j];
+              if (rn) v[k][j] += rv[qq][k][j];
               if (!FULL) asm volatile("" : "+v"(v[k][j]));
             }
+          if (!MSHUFFLE && a.gn_sums) {
+            // statistics of the following GroupNorm from the values being stored: the 4 channels of this batch
+            // lie in one group
+            float sj[NI], qj[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) { sj[j] = 0.f; qj[j] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int j = 0; j < NI; ++j) {
+                const float u = (FULL || (cok[k] && rowok[j])) ? v[k][j] : 0.f;
+                sj[j] += u;
+                qj[j] = __builtin_fmaf(u, u, qj[j]);
+              }
+            float sv = sj[0], qv = qj[0];
+#pragma unroll
+            for (int j = 1; j < NI; ++j) { sv += sj[j]; qv += qj[j]; }
+            // quad sums by DPP, then one plain store per quad into this wave's own cells (LDS float atomics cost
+            // +9 % kernel time at 128 channels; plain stores are free)
+            sv += dpp_quad<0xB1>(sv); qv += dpp_quad<0xB1>(qv);      // lane ^ 1
+            sv += dpp_quad<0x4E>(sv); qv += dpp_quad<0x4E>(qv);      // lane ^ 2
+            if ((lane & 3) == 0) {
+              float* cell = gslot + (wave * 16 + i * 4 + qq) * 16 + (lane >> 2);
+              cell[0] = sv;
+              cell[8 * 16] = qv;
+            }
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -577,7 +633,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   }
   zero_acc();
   stage_barrier(IC0{});
-  int xbuf = 0;   // halo buffer of the chunk being multiplied (XDB)
+  int xbuf = 0;
+  bool gn_pend = false;   // a stored tile's GroupNorm partials wait in LDS for the next barrier
+  int gn_n = 0, gn_cob = 0;   // halo buffer of the chunk being multiplied (XDB)
 
   int q = 0;  // global stage counter: ring half (q & 1) holds the stage being multiplied
 #if EOVAE_C8_STAMP
@@ -691,6 +749,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
           stage_barrier(IC0{});
         }
         C8_STAMP(7);
+        if (!MSHUFFLE && gn_pend) {   // uniform; first barrier behind the epilogue that filled the slots
+          gn_flush(gn_n, gn_cob);
+          gn_pend = false;
+        }
 #if EOVAE_C8_STAMP
         ++rec;
 #endif
@@ -703,6 +765,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #endif
     epilogue_tile(cur);
     zero_acc();
+    if (!MSHUFFLE && a.gn_sums) { gn_pend = true; gn_n = cur.n; gn_cob = cur.cob; }
 #if EOVAE_C8_STAMP
     C8_STAMP(7);
     if (lane == 0 && blockIdx.x < C8_NBLK && rec < C8_MAXREC)   // 100 MHz wall clock next to the shader clock
@@ -710,6 +773,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     ++rec;
 #endif
     cur = nxt;
+  }
+  if (!MSHUFFLE && gn_pend) {
+    stage_barrier(IC0{});
+    gn_flush(gn_n, gn_cob);
   }
 }
 
@@ -1383,7 +1450,8 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
 // (eovae_absmax_bits) when x may sit outside f16's range (gradients), else NULL.
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual, float* y,
                             const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
-                            int Wout, int mode, int subpix, int xpacked, void* stream) {
+                            int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
+                            void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_f16c8_fwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_f16c8_fwd: bad shape");
   EOVAE_CHECK_ARG(mode == MODE_NORMAL, "conv3x3_f16c8_fwd: mode %d unsupported (stride-1 'normal' layers and the "
@@ -1417,6 +1485,15 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   }
   const int kreal = (subpix == 2 || subpix == 3) ? a.creal : a.Cin;
   EOVAE_CHECK_ARG(kreal % 32 == 0, "conv3x3_f16c8_fwd: K channels (%d) must be a multiple of 32", kreal);
+  a.gn_sums = gn_sums; a.gn_groups = gn_groups; a.gn_shift = 0;
+  if (gn_sums) {   // GroupNorm statistics of y from the epilogue: groups of 4 .. 128 channels, a power of two
+    const int cpg = gn_groups > 0 && a.Cout % gn_groups == 0 ? a.Cout / gn_groups : 0;
+    EOVAE_CHECK_ARG(cpg >= 4 && cpg <= 128 && (cpg & (cpg - 1)) == 0,
+                    "conv3x3_f16c8_fwd: gn_sums needs Cout / gn_groups in {4, 8, ..., 128} (Cout %d, groups %d)", a.Cout,
+                    gn_groups);
+    EOVAE_CHECK_ARG(subpix == 0 || subpix == 2 || subpix == 3, "conv3x3_f16c8_fwd: gn_sums with subpix %d", subpix);
+    while ((1 << a.gn_shift) < cpg) ++a.gn_shift;
+  }
   Cin = a.Cin; Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
   a.nchunk = Cin / 32; a.ncob = cdiv(Cout, 128);
   a.tiles_x = cdiv(Wout, 32);

@@ -339,8 +339,11 @@ size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G) {
 }
 
 // stats[N*G][2] = (mean, rstd) is written and must be kept for the backward
+// sums (optional): [N*G][2] doubles (sum, sum of squares) of x per (image, group) that the kernel which WROTE x
+// has already accumulated (eovae_conv3x3_f16c8_fwd's gn_sums) -- the statistics pass over x is then skipped.
 int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
-                      int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream) {
+                      const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
+                      void* stream) {
   EOVAE_CHECK_ARG(x && gamma && beta && y && stats && ws, "gn_silu_fwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "gn_silu_fwd: C=%d G=%d", C, G);
   hipStream_t st = (hipStream_t)stream;
@@ -348,9 +351,9 @@ int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, flo
   const size_t gsize = (size_t)cpg * HW;
   const int ns = nsplit_for(gsize);
   double* part = (double*)ws;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats,
-                     N * G, ns, 1.0 / (double)gsize, eps);
+  if (!sums) hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, sums ? sums : part, stats,
+                     N * G, sums ? 1 : ns, 1.0 / (double)gsize, eps);
   const int chunks = chunks_for(HW);
   if (silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(N * C * chunks), dim3(256), 0, st, x, gamma, beta,
@@ -365,7 +368,8 @@ int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, flo
 // As eovae_gn_silu_fwd, but the output is written as f16c8 operand records (see gn_apply_packed_kernel):
 // pa has N*C*HW dwords (the size of the fp32 output it replaces); C must be a multiple of 8.
 int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
-                             int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream) {
+                             const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
+                             void* stream) {
   EOVAE_CHECK_ARG(x && gamma && beta && pa && stats && ws, "gn_silu_fwd_packed: null pointer");
   EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C % 8 == 0, "gn_silu_fwd_packed: C=%d G=%d", C, G);
   hipStream_t st = (hipStream_t)stream;
@@ -373,9 +377,9 @@ int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* be
   const size_t gsize = (size_t)cpg * HW;
   const int ns = nsplit_for(gsize);
   double* part = (double*)ws;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats,
-                     N * G, ns, 1.0 / (double)gsize, eps);
+  if (!sums) hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, sums ? sums : part, stats,
+                     N * G, sums ? 1 : ns, 1.0 / (double)gsize, eps);
   const int pblocks = cdiv(HW, 256);
   if (silu)
     hipLaunchKernelGGL(gn_apply_packed_kernel<true>, dim3(N * (C / 8) * pblocks), dim3(256), 0, st, x, gamma, beta,

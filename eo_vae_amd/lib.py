@@ -31,9 +31,9 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_packed_bytes': (_sz, [_i, _i, _i]),
     'eovae_conv3x3_f16c8_pack': (_i, [_p, _p, _i, _i, _i, _f, _p]),
     'eovae_conv3x3_f16c8_pack_pair': (_i, [_p, _p, _p, _i, _i, _f, _p]),
-    'eovae_conv3x3_f16c8_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'eovae_conv3x3_f16c8_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    'eovae_gn_silu_fwd_packed': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
+    'eovae_gn_silu_fwd_packed': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_subpix_expand': (_i, [_p, _p, _i, _i, _p]),
     'eovae_down_expand': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_down_fold': (_i, [_p, _p, _i, _i, _p]),
@@ -44,7 +44,7 @@ SIGNATURES = {
     'eovae_bias_grad': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_upsample2x_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'eovae_gn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
+    'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
@@ -83,7 +83,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 6  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

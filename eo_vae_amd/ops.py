@@ -184,6 +184,31 @@ def packed_ok(channels):
 PACKED_ACTIVATIONS = os.environ.get('EOVAE_PACKED_ACT', '1') != '0'
 
 
+# Every 3x3 convolution of the model is followed by a GroupNorm(32) over its output (layers.py:91-92, 106-108;
+# model.py norm_out): the f16c8 forward kernel adds that GroupNorm's (sum, sum of squares) per (image, group) from
+# its epilogue, and the tag below lets group_norm_silu() skip its statistics pass over the tensor.
+GN_FUSED_STATS = os.environ.get('EOVAE_GN_FUSED', '1') != '0'
+GN_GROUPS_HINT = 32
+_LAST_GN_SUMS = None   # handed from Conv2dFn.forward to conv2d(), which tags the tensor autograd returns
+
+
+def _gn_sums_buffer(n, cout, device):
+    """Zeroed [n, 32, 2] float64 accumulator when the epilogue can produce the statistics, else None."""
+    cpg = cout // GN_GROUPS_HINT if cout % GN_GROUPS_HINT == 0 else 0
+    if not GN_FUSED_STATS or cpg < 4 or cpg > 128 or cpg & (cpg - 1):
+        return None
+    return torch.zeros(n, GN_GROUPS_HINT, 2, dtype=torch.float64, device=device)
+
+
+def gn_sums_of(x, groups):
+    """The producer's (sum, sumsq) accumulator for GroupNorm(groups) over x, if x still is what was summed."""
+    tag = getattr(x, '_eovae_gn_sums', None)
+    if tag is not None and tag[1] == groups and tag[2] == x._version and tag[0].shape[0] == x.shape[0] \
+            and tag[0].device == x.device:
+        return tag[0]
+    return None
+
+
 def amax_of(t):
     """absmax bits of t: the producer's tag when it is still valid, else one reduction pass."""
     tag = getattr(t, '_eovae_amax', None)
@@ -209,14 +234,15 @@ def _pack3x3(w4, rows, cols, flip, f16c8):
 
 
 def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None,
-               packed=False):
+               packed=False, gn_sums=None):
     lib = L.load()
     if packed and not f16c8:
         raise L.EovaeError('conv2d: operand-record input reached a non-f16c8 kernel')
     if f16c8:
         L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
                                             L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
-                                            int(packed), L.stream()), 'eovae_conv3x3_f16c8_fwd')
+                                            int(packed), L.ptr(gn_sums), GN_GROUPS_HINT if gn_sums is not None else 0,
+                                            L.stream()), 'eovae_conv3x3_f16c8_fwd')
     else:
         L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
                                            cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], subpix,
@@ -269,8 +295,11 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
         ev0.record()
     if packed and not f8:
         raise L.EovaeError('conv2d: operand-record input needs the f16c8 kernel (K % 32 == 0, mode normal)')
+    global _LAST_GN_SUMS
+    sums = _gn_sums_buffer(n, cout_gemm, x.device) if f8 and not flip else None
     _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, amax if flip else None,
-               packed)
+               packed, sums)
+    _LAST_GN_SUMS = sums
     if timed:
         ev1.record()
     return y
@@ -316,7 +345,10 @@ def down_conv_s2d(x, weight, bias):
     f8 = _use_f16c8(cin)
     wp = _down_packed(weight, False, f8)
     y = torch.empty(n, cout, h // 2, w // 2, dtype=torch.float32, device=x.device)
-    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 3, f8)
+    global _LAST_GN_SUMS
+    sums = _gn_sums_buffer(n, cout, x.device) if f8 else None
+    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 3, f8, gn_sums=sums)
+    _LAST_GN_SUMS = sums
     return y
 
 
@@ -546,7 +578,13 @@ class Conv2dFn(torch.autograd.Function):
 
 
 def conv2d(x, weight, bias=None, residual=None, mode='normal'):
-    return Conv2dFn.apply(x, weight, bias, residual, mode)
+    global _LAST_GN_SUMS
+    _LAST_GN_SUMS = None
+    y = Conv2dFn.apply(x, weight, bias, residual, mode)
+    if _LAST_GN_SUMS is not None:
+        y._eovae_gn_sums = (_LAST_GN_SUMS, GN_GROUPS_HINT, y._version)
+        _LAST_GN_SUMS = None
+    return y
 
 
 # ------------------------------------------------------------------------------------------
@@ -561,8 +599,8 @@ def _gn_forward(x, gamma, beta, groups, eps, silu, packed):
     y = torch.empty_like(x)
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
     fn = lib.eovae_gn_silu_fwd_packed if packed else lib.eovae_gn_silu_fwd
-    L.check(fn(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), n, c, h * w, groups, eps, int(silu),
-               L.ptr(ws), L.stream()), 'eovae_gn_silu_fwd')
+    L.check(fn(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), L.ptr(gn_sums_of(x, groups)), n, c,
+               h * w, groups, eps, int(silu), L.ptr(ws), L.stream()), 'eovae_gn_silu_fwd')
     return y, stats
 
 

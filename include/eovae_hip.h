@@ -83,7 +83,13 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
                                   void* stream);
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
-                            int Hout, int Wout, int mode, int subpix, int xpacked, void* stream);
+                            int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
+                            void* stream);
+/* gn_sums (nullable; forward calls, subpix 0 / 2 / 3): [N][gn_groups][2] doubles, zero-filled by the caller; the
+ * epilogue adds (sum, sum of squares) of the values it stores (bias and residual included) per image and channel
+ * group, i.e. the statistics pass of the GroupNorm(gn_groups) that reads y next (layers.py:91-92, 106-108 follow
+ * every conv with one) -- hand the array to eovae_gn_silu_fwd[_packed] as `sums` and that call does not read y
+ * a second time.  Cout / gn_groups must be a power of two in 4..128. */
 /* f16c8 weight gradient (same tiling and sub-pixel forms as eovae_conv3x3_bf16_wgrad; replaces the same
  * autograd call site of F.conv2d, layers.py:29-50, 70-110): per 32 pixels and tap 2 f16 MFMAs + 1 block-scaled
  * fp8 MFMA [dy_lo|dy_hi].[x_hi|x_lo].  dyamax as for the data gradient (NULL = dy used unscaled). */
@@ -98,7 +104,8 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
  * gradient of plain 3x3 layers only (subpix 0, mode 0; wgrad: Cin %% 64 == 0).  Replaces the
  * `h = conv(swish(norm(h)))` pairs of layers.py:91-111 and model.py:193-196, 349-357. */
 int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
-                             int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream);
+                             const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
+                             void* stream);
 /* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);
@@ -132,8 +139,11 @@ int eovae_upsample2x_bwd(const float* du, float* dx, int N, int C, int H, int W,
  * stats[N*G][2] = (mean, rstd) is produced by the forward and consumed by the backward.
  * -------------------------------------------------------------------------------------- */
 size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G);
+/* sums (nullable): [N*G][2] doubles (sum, sum of squares) of x per (image, group) already accumulated by the
+ * kernel that wrote x (eovae_conv3x3_f16c8_fwd gn_sums); NULL = computed here by a pass over x */
 int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
-                      int N, int C, int HW, int G, float eps, int silu, void* ws, void* stream);
+                      const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
+                      void* stream);
 /* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C]; dx_amax_bits (nullable, device): receives the
  * float bits of max|dx| -- the pre-scale input of eovae_conv3x3_f16c8_fwd's data-gradient calls, produced
  * here for free instead of by a separate eovae_absmax_bits pass over dx */

@@ -197,3 +197,40 @@ def test_groupnorm_operand_records_equal_the_fp32_hand_over(n, c, cout, h, w):
                        hashed((cout, c, 1, 1), 17, 0.1).cuda(), None, None, 'normal')
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,res,mode', [
+    (2, 64, 128, 20, 44, False, 'normal'),      # 4 channels per group, ragged tiles
+    (2, 128, 256, 32, 32, True, 'normal'),      # 8 per group: the two lane halves share a group
+    (1, 64, 512, 17, 33, True, 'normal'),       # 16 per group, 4 co-blocks
+    (3, 128, 128, 64, 64, True, 'normal'),      # several tiles per persistent block
+    (2, 128, 128, 32, 48, False, 'down'),       # space-to-depth stride-2 form
+])
+def test_conv_epilogue_groupnorm_sums(n, cin, cout, h, w, res, mode):
+    """f16c8 forward: the (sum, sum of squares) per (image, group of Cout/32 channels) that the epilogue adds up
+    for the following GroupNorm must equal the sums over the tensor it stored, and a GroupNorm fed with the tag
+    must equal a GroupNorm that measures the tensor itself (reference layers.py:91-92: norm reads conv's output)."""
+    from eo_vae_amd import ops
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 'f16c8'
+    try:
+        x = hashed((n, cin, h, w), 21, 1.0).cuda()
+        wt, b = hashed((cout, cin, 3, 3), 22, 1.0 / (cin * 9) ** 0.5).cuda(), hashed((cout,), 23, 0.5).cuda()
+        ho, wo = (h // 2, w // 2) if mode == 'down' else (h, w)
+        r = hashed((n, cout, ho, wo), 24, 1.0).cuda() if res else None
+        y = ops.conv2d(x, wt, b, r, mode)
+        sums = ops.gn_sums_of(y, 32)
+        assert sums is not None and sums.dtype == torch.float64 and tuple(sums.shape) == (n, 32, 2)
+        yd = y.double().view(n, 32, -1)
+        want = torch.stack([yd.sum(-1), (yd * yd).sum(-1)], -1)
+        torch.cuda.synchronize()
+        assert (sums - want).abs().max() <= 2e-6 * want.abs().max()
+        gam, bet = (1.0 + hashed((cout,), 25, 0.2)).cuda(), hashed((cout,), 26, 0.2).cuda()
+        a_tag = ops.group_norm_silu(y, gam, bet, 32, 1e-6, True)
+        a_own = ops.group_norm_silu(y.clone(), gam, bet, 32, 1e-6, True)        # clone: no tag
+        assert ops.gn_sums_of(y.clone(), 32) is None and ops.gn_sums_of(y, 16) is None
+        assert rel_err(a_tag.cpu(), a_own.cpu()) < 2e-6
+        y.add_(1.0)                                                             # edited in place: tag is void
+        assert ops.gn_sums_of(y, 32) is None
+    finally:
+        ops.CONV_PRECISION = old

@@ -15,7 +15,7 @@ y = torch.empty(B, cout, hw, hw, device='cuda')
 wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
 L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
 for _ in range(20):   # warm: clocks settle under load
-    L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, L.stream()), 'fwd')
+    L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()), 'fwd')
 torch.cuda.synchronize()
 NPT, MAXREC, NBLK = 8, 96, 4
 buf = np.zeros(NBLK * 8 * MAXREC * NPT, dtype=np.uint64)

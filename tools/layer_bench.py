@@ -24,6 +24,7 @@ for cin, cout, hw in shapes:
     dy = torch.randn(B, cout, hw, hw, device='cuda')
     y = torch.empty_like(dy)
     res = torch.randn_like(dy) if os.environ.get('LB_RES') == '1' else None   # conv2 of a ResnetBlock adds its skip
+    gns = torch.zeros(B, 32, 2, dtype=torch.float64, device='cuda') if os.environ.get('LB_GN') == '1' else None   # GroupNorm sums from the epilogue
     flops = 2.0 * B * hw * hw * cin * cout * 9
     fns = {}
     for prec in precs:
@@ -32,7 +33,7 @@ for cin, cout, hw in shapes:
             L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
             dwp8 = torch.zeros(9 * cout * cin, device='cuda')
             amax = ops.absmax_bits(dy)
-            fns[prec] = (lambda wp=wp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.stream()),
+            fns[prec] = (lambda wp=wp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.ptr(gns), 32 if gns is not None else 0, L.stream()),
                          lambda dwp8=dwp8, amax=amax: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp8), None, L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.stream()))
         else:
             p = ops._PREC[prec]
