@@ -484,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   // gn_flush() folds the 4 row waves x 8 quads behind each (channel quartet, value) and adds the result to
   // gn_sums[n][group] in double.  Every cell is rewritten by the next epilogue, several barriers later.
   float* const gslot = reinterpret_cast<float*>(smem + OFF_W + 4 * WTAP);
-  auto gn_flush = [&](int tn, int tcob) __attribute__((always_inline)) {
+  auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {   // tcb: first (real) channel of the block
     const int out = tid >> 3, sub = tid & 7;
     const int v = out >> 5, wc = (out >> 4) & 1, b = (out >> 1) & 7, hh = out & 1;
     const int w = (sub >> 1) * 2 + wc;
@@ -493,8 +493,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     t += dpp_quad<0xB1>(t);
     t += dpp_quad<0x4E>(t);
     t += __shfl_xor(t, 4, 8);
-    const int co = tcob * BM + wc * 64 + (b >> 2) * 32 + (b & 3) * 8 + 4 * hh;
-    if (sub == 0 && co < a.Cout)
+    const int co = tcb + wc * 64 + (b >> 2) * 32 + (b & 3) * 8 + 4 * hh;
+    if (sub == 0 && co < (MSHUFFLE ? a.creal : a.Cout))
       atomicAdd(a.gn_sums + ((size_t)tn * a.gn_groups + (co >> a.gn_shift)) * 2 + v, (double)t);
   };
 
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
               if (rn) v[k][j] += rv[qq][k][j];
               if (!FULL) asm volatile("" : "+v"(v[k][j]));
             }
-          if (!MSHUFFLE && a.gn_sums) {
+          if (a.gn_sums) {
             // statistics of the following GroupNorm from the values being stored: the 4 channels of this batch
             // lie in one group
             float sj[NI], qj[NI];
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   stage_barrier(IC0{});
   int xbuf = 0;
   bool gn_pend = false;   // a stored tile's GroupNorm partials wait in LDS for the next barrier
-  int gn_n = 0, gn_cob = 0;   // halo buffer of the chunk being multiplied (XDB)
+  int gn_n = 0, gn_cb = 0;   // halo buffer of the chunk being multiplied (XDB)
 
   int q = 0;  // global stage counter: ring half (q & 1) holds the stage being multiplied
 #if EOVAE_C8_STAMP
@@ -749,8 +749,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
           stage_barrier(IC0{});
         }
         C8_STAMP(7);
-        if (!MSHUFFLE && gn_pend) {   // uniform; first barrier behind the epilogue that filled the slots
-          gn_flush(gn_n, gn_cob);
+        if (gn_pend) {   // uniform; first barrier behind the epilogue that filled the cells
+          gn_flush(gn_n, gn_cb);
           gn_pend = false;
         }
 #if EOVAE_C8_STAMP
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #endif
     epilogue_tile(cur);
     zero_acc();
-    if (!MSHUFFLE && a.gn_sums) { gn_pend = true; gn_n = cur.n; gn_cob = cur.cob; }
+    if (a.gn_sums) { gn_pend = true; gn_n = cur.n; gn_cb = (MSHUFFLE ? cur.cob - cur.par1 * a.cpb : cur.cob) * BM; }
 #if EOVAE_C8_STAMP
     C8_STAMP(7);
     if (lane == 0 && blockIdx.x < C8_NBLK && rec < C8_MAXREC)   // 100 MHz wall clock next to the shader clock
@@ -774,9 +774,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #endif
     cur = nxt;
   }
-  if (!MSHUFFLE && gn_pend) {
+  if (gn_pend) {
     stage_barrier(IC0{});
-    gn_flush(gn_n, gn_cob);
+    gn_flush(gn_n, gn_cb);
   }
 }
 
@@ -1487,11 +1487,11 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   EOVAE_CHECK_ARG(kreal % 32 == 0, "conv3x3_f16c8_fwd: K channels (%d) must be a multiple of 32", kreal);
   a.gn_sums = gn_sums; a.gn_groups = gn_groups; a.gn_shift = 0;
   if (gn_sums) {   // GroupNorm statistics of y from the epilogue: groups of 4 .. 128 channels, a power of two
-    const int cpg = gn_groups > 0 && a.Cout % gn_groups == 0 ? a.Cout / gn_groups : 0;
+    const int creal = (subpix == 1 || subpix == 4) ? a.creal : a.Cout;   // channels of the tensor being written
+    const int cpg = gn_groups > 0 && creal % gn_groups == 0 ? creal / gn_groups : 0;
     EOVAE_CHECK_ARG(cpg >= 4 && cpg <= 128 && (cpg & (cpg - 1)) == 0,
-                    "conv3x3_f16c8_fwd: gn_sums needs Cout / gn_groups in {4, 8, ..., 128} (Cout %d, groups %d)", a.Cout,
+                    "conv3x3_f16c8_fwd: gn_sums needs Cout / gn_groups in {4, 8, ..., 128} (Cout %d, groups %d)", creal,
                     gn_groups);
-    EOVAE_CHECK_ARG(subpix == 0 || subpix == 2 || subpix == 3, "conv3x3_f16c8_fwd: gn_sums with subpix %d", subpix);
     while ((1 << a.gn_shift) < cpg) ++a.gn_shift;
   }
   Cin = a.Cin; Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;

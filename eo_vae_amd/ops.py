@@ -385,7 +385,10 @@ def up_conv_subpix(x, weight, bias):
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
                                          4.0 * (x.numel() + y.numel() + weight.numel()))
         ev0.record()
-    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8)
+    global _LAST_GN_SUMS
+    sums = _gn_sums_buffer(n, cout, x.device) if f8 else None
+    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8, gn_sums=sums)
+    _LAST_GN_SUMS = sums
     if timed:
         ev1.record()
     return y

@@ -85,7 +85,7 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                             void* stream);
-/* gn_sums (nullable; forward calls, subpix 0 / 2 / 3): [N][gn_groups][2] doubles, zero-filled by the caller; the
+/* gn_sums (nullable; meant for the forward calls, any subpix form): [N][gn_groups][2] doubles, zero-filled by the caller; the
  * epilogue adds (sum, sum of squares) of the values it stores (bias and residual included) per image and channel
  * group, i.e. the statistics pass of the GroupNorm(gn_groups) that reads y next (layers.py:91-92, 106-108 follow
  * every conv with one) -- hand the array to eovae_gn_silu_fwd[_packed] as `sums` and that call does not read y

@@ -205,6 +205,8 @@ def test_groupnorm_operand_records_equal_the_fp32_hand_over(n, c, cout, h, w):
     (1, 64, 512, 17, 33, True, 'normal'),       # 16 per group, 4 co-blocks
     (3, 128, 128, 64, 64, True, 'normal'),      # several tiles per persistent block
     (2, 128, 128, 32, 48, False, 'down'),       # space-to-depth stride-2 form
+    (2, 64, 256, 12, 20, False, 'up'),          # sub-pixel upsample form (pixel-shuffled store)
+    (1, 128, 128, 32, 32, False, 'up'),
 ])
 def test_conv_epilogue_groupnorm_sums(n, cin, cout, h, w, res, mode):
     """f16c8 forward: the (sum, sum of squares) per (image, group of Cout/32 channels) that the epilogue adds up
@@ -216,7 +218,7 @@ def test_conv_epilogue_groupnorm_sums(n, cin, cout, h, w, res, mode):
     try:
         x = hashed((n, cin, h, w), 21, 1.0).cuda()
         wt, b = hashed((cout, cin, 3, 3), 22, 1.0 / (cin * 9) ** 0.5).cuda(), hashed((cout,), 23, 0.5).cuda()
-        ho, wo = (h // 2, w // 2) if mode == 'down' else (h, w)
+        ho, wo = (h // 2, w // 2) if mode == 'down' else ((2 * h, 2 * w) if mode == 'up' else (h, w))
         r = hashed((n, cout, ho, wo), 24, 1.0).cuda() if res else None
         y = ops.conv2d(x, wt, b, r, mode)
         sums = ops.gn_sums_of(y, 32)
