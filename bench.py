@@ -52,7 +52,7 @@ def pmc_traffic(kernel):
     the fold was taken on THIS build of the kernels (same digest of eo_vae_amd/csrc); otherwise traffic is
     null and the source says why -- a stale file is never passed off as a measurement."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))   # by round tag (mtimes do not travel)
     for f in reversed(files):
         try:
             with open(f) as fh:
@@ -66,6 +66,11 @@ def pmc_traffic(kernel):
                'fetch_bytes_raw': k.get('fetch_bytes_raw_per_launch'), 'write_bytes': k.get('write_bytes_per_launch'),
                'note': 'FETCH_SIZE x2 (gfx950 correction, calibrated for 16-B/lane streams; halo loads are dword/lane, '
                        'so the true figure lies between raw and corrected)'}
+        from eo_vae_amd import ops
+        if d.get('conv_precision', ops.DEFAULT_PRECISION) != ops.CONV_PRECISION:
+            src['stale'] = (f"fold measured in conv precision {d.get('conv_precision', ops.DEFAULT_PRECISION)!r}, "
+                            f'this run is {ops.CONV_PRECISION!r}')
+            return None, src
         if d.get('csrc_digest') == src['build_digest']:
             return k['traffic_bytes_per_launch_corrected'], src
         src['stale'] = 'kernel sources changed since this fold was measured'

@@ -21,6 +21,7 @@ for f in sorted(glob.glob(os.path.join(repo, 'eo_vae_amd', 'csrc', '*'))):   # t
     h.update(os.path.basename(f).encode())
     h.update(open(f, 'rb').read())
 out['csrc_digest'] = h.hexdigest()[:16]
+out['conv_precision'] = os.environ.get('EOVAE_CONV_PRECISION', 'f16c8')   # arithmetic mode of the profiled run
 for k, d in acc.items():
     f, w = d.get('FETCH_SIZE', []), d.get('WRITE_SIZE', [])
     if not f or not w:
