@@ -909,21 +909,50 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   // (0.26-0.35 ms + 0.6-0.7 ms = 1.0-1.2 ms); doubling the prefetch distance from one k-step to two
   // measured +0..3 % on the same box, so load LATENCY is not what serialises them.
   // dY: 2 tasks (4 channels x 1 pixel) per thread; X halo: 640 tasks (8 channels x 1 pixel).
-  constexpr int XHALF = NXP * 8 / 2;   // 640
+  // Task maps are powers of two so that no per-tile integer division is left in the loop (the r1 maps cost ~400
+  // index-math VALU instructions per thread and tile; SQ counters: VALU 2 x 23 % and MFMA 38 % of a SIMD's cycles,
+  // adding up):
+  //   dY  : thread -> (pixel tid & 15 of x-half i, channel quartet tid >> 4); 2 tasks per half tile
+  //   halo: half hf stages ci-tile hf = octets 4 hf .. 4 hf + 3 over the 160 halo pixels (4 rows x 40, 34 valid):
+  //         round 0 (all threads): octet tid >> 7, pixel tid & 127; round 1 (tid < 128): octet tid >> 5, pixel
+  //         128 + (tid & 31), i.e. halo row 3, columns 8..39
+  // and everything that depends on the tile only is wave-uniform (scalar base pointers, 32-bit lane offsets).
   float dyr[2][4], xr[2][8];
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};  // bias-gradient partials of this thread's 4 channels
   const bool do_db = a.db != nullptr && cib == 0 && SUBPIX != 1;
-  unsigned vmask = 0xf;  // bit i: dY task i valid; bit 2+i: X task i valid (set by issue*, used by commit)
+  bool okd0 = true, okd1 = true, okx0 = true, okx1 = true;  // validity of the staged tasks (lane masks in SGPRs)
+  const int pixl = tid & 15, quad = tid >> 4;
+  auto xgeom = [&](int i, int& octr, int& pix, int& rr, int& cc, bool& active) __attribute__((always_inline)) {
+    if (i == 0) {
+      octr = tid >> 7;
+      pix = tid & 127;
+      rr = (pix * 205) >> 13;          // pix / 40 for pix < 128
+      cc = pix - 40 * rr;
+      active = true;
+    } else {
+      octr = (tid >> 5) & 3;
+      pix = 128 + (tid & 31);
+      rr = 3;
+      cc = 8 + (tid & 31);
+      active = tid < 128;
+    }
+  };
+  struct TileC { int n, oy0, ox0; };
+  auto decode = [&](int tile) __attribute__((always_inline)) {
+    TileC t;
+    const int tx = tile % a.tiles_x;
+    tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    t.n = tile / a.tiles_y;
+    t.oy0 = ty * 2;
+    t.ox0 = tx * PW;
+    return t;
+  };
   auto issue = [&](int tile, int hf) __attribute__((always_inline)) {
-    int t = tile;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int n = t / a.tiles_y;
-    const int oy0 = ty * 2, ox0 = tx * PW;
+    const TileC tc = decode(tile);
+    const int n = tc.n, oy0 = tc.oy0, ox0 = tc.ox0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pixl = tid & 15, quad = tid >> 4;      // 32 quads x 16 pixels, x-half i
       const int oy = oy0 + hf, ox = ox0 + 16 * i + pixl;
       const bool ok = oy < a.Hout && ox < a.Wout;
       const size_t pixoff = SUBPIX == 1 ? (size_t)(2 * oy + py) * (2 * a.Wout) + 2 * ox + px
@@ -938,11 +967,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int tt = tid + i * 512;
-      if (tt < XHALF) {
-        const int t2 = hf * XHALF + tt;
-        const int oct = t2 / NXP, pix = t2 - oct * NXP;
-        const int rr = pix / XW, cc = pix - rr * XW;
+      int octr, pix, rr, cc;
+      bool active;
+      xgeom(i, octr, pix, rr, cc, active);
+      if (active) {
+        const int oct = hf * 4 + octr;
         int si = -1;
         if (cc < XWV) {
           if (SUBPIX == 2) {  // space-to-depth gather: low-res halo pixel (vy,vx) -> x[2vy+py][2vx+px]
@@ -974,88 +1003,88 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         }
       }
     }
-    vmask = 0xf;  // zeros already selected
+    okd0 = okd1 = okx0 = okx1 = true;  // zeros already selected
   };
-  // Fast path (every channel of the block's 128 co x 64 ci slab exists -- all layers of the model):
-  // UNCONDITIONAL loads from clamped addresses, validity kept as 4 mask bits and applied when the
-  // registers are converted.  Predicated loads (`ok ? p[i] : 0`) compile to an exec-mask branch per
-  // load plus vmcnt(0) drains between them, i.e. several fully exposed memory latencies per half tile.
-  const bool fullc = cob * 128 + 128 <= a.Cout && cib * 64 + 64 <= a.Cin;
+  // Fast path (every channel of the block's 128 co x 64 ci slab exists and the layer is not the fused-upsample
+  // form -- all layers of the model): UNCONDITIONAL loads, validity kept as lane masks and applied when the
+  // registers are converted (predicated loads compile to an exec-mask branch per load plus vmcnt(0) drains).
+  // Address = wave-uniform pointer (image, tile origin, channel j / ci-tile: scalar ALU) + a 32-bit lane offset
+  // that is a per-thread constant for valid lanes and the tile-origin pixel for the others.
+  const bool fullc = cob * 128 + 128 <= a.Cout && cib * 64 + 64 <= a.Cin && a.mode == MODE_NORMAL;
   const float* dyb = a.dy + (size_t)(cob * 128 - (SUBPIX == 1 ? par * a.creal : 0)) * out_plane;
   const float* xb = a.x + (size_t)(cib * 64 - (SUBPIX == 2 ? par * a.creal : 0)) * in_plane;
+  constexpr int PST = SUBPIX == 1 ? 2 : 1;        // dy pixel stride (sub-pixel form: every other high-res pixel)
+  const unsigned dq = (unsigned)quad * 4u * (unsigned)out_plane;
   auto issue_fast = [&](int tile, int hf) __attribute__((always_inline)) {
-    int t = tile;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int n = t / a.tiles_y;
-    const int oy0 = ty * 2, ox0 = tx * PW;
+    const TileC tc = decode(tile);
+    const int n = tc.n, oy0 = tc.oy0, ox0 = tc.ox0;
     const int xch = SUBPIX == 2 ? a.creal : a.Cin;
     const float* dyn = dyb + (size_t)n * dych * out_plane;   // wave-uniform bases
-    const float* xn = xb + (size_t)n * xch * in_plane;
-    unsigned m = 0;
+    const int oy = oy0 + hf;
+    const bool rowok = oy < a.Hout;
+    const unsigned rowoff = SUBPIX == 1 ? (unsigned)((2 * oy + py) * (2 * a.Wout) + px) : (unsigned)(oy * a.Wout);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pixl = tid & 15, quad = tid >> 4;
-      const int oy = oy0 + hf, ox = ox0 + 16 * i + pixl;
-      const bool ok = oy < a.Hout && ox < a.Wout;
-      const unsigned pixoff = !ok ? 0u
-                              : (SUBPIX == 1 ? (unsigned)((2 * oy + py) * (2 * a.Wout) + 2 * ox + px)
-                                             : (unsigned)(oy * a.Wout + ox));
-      m |= (ok ? 1u : 0u) << i;
-      const float* src = dyn + (size_t)(quad * 4) * out_plane + pixoff;
+      const int oxb = ox0 + 16 * i;
+      const bool cok = rowok && oxb < a.Wout;                              // uniform
+      const float* sb = dyn + (cok ? rowoff + (unsigned)(PST * oxb) : 0u);  // off-grid: pixel 0 of the image
+      const bool ok = cok && pixl < a.Wout - oxb;
+      const unsigned vo = dq + (ok ? (unsigned)(PST * pixl) : 0u);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dyr[i][j] = src[(size_t)j * out_plane];
+      for (int j = 0; j < 4; ++j) dyr[i][j] = (sb + (size_t)j * out_plane)[vo];
+      if (i == 0) okd0 = ok; else okd1 = ok;
     }
+    // halo: pixel (rr, cc) of the tile's halo sits at origin + rr * ys + cc * xs of its plane
+    const int ys = SUBPIX == 2 ? 2 * a.Win : a.Win, xs = SUBPIX == 2 ? 2 : 1;
+    const int lh = SUBPIX == 2 ? a.Hout : a.Hin, lw = SUBPIX == 2 ? a.Wout : a.Win;
+    const long origin = SUBPIX == 2 ? (long)(2 * (oy0 - 1) + py) * a.Win + 2 * (ox0 - 1) + px
+                                    : (long)(oy0 - 1) * a.Win + (ox0 - 1);
+    const unsigned lin_safe = (unsigned)(ys + xs);           // halo (1, 1) = the tile's first pixel: always inside
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int tt = tid + i * 512;
-      const int t2 = hf * XHALF + (tt < XHALF ? tt : 0);
-      const int oct = t2 / NXP, pix = t2 - oct * NXP;
-      const int rr = pix / XW, cc = pix - rr * XW;
-      int si = -1;
-      if (cc < XWV && tt < XHALF) {
-        if (SUBPIX == 2) {
-          const int vy = oy0 + rr - 1, vx = ox0 + cc - 1;
-          if ((unsigned)vy < (unsigned)a.Hout && (unsigned)vx < (unsigned)a.Wout)
-            si = (2 * vy + py) * a.Win + 2 * vx + px;
-        } else {
-          si = wg_src_index(a.mode, oy0, ox0, rr, cc, a.Hin, a.Win);
-        }
-      }
-      m |= (si >= 0 ? 1u : 0u) << (2 + i);
-      const float* src = xn + (size_t)(oct * 8) * in_plane + (si >= 0 ? si : 0);
-      if (i == 0 || tid < XHALF - 512) {   // second round: 128 of the 512 threads
+      int octr, pix, rr, cc;
+      bool active;
+      xgeom(i, octr, pix, rr, cc, active);
+      const bool ok = active && cc < XWV && (unsigned)(oy0 + rr - 1) < (unsigned)lh &&
+                      (unsigned)(ox0 + cc - 1) < (unsigned)lw;
+      const unsigned lin = ok ? (unsigned)(rr * ys + cc * xs) : lin_safe;
+      if (i == 0) okx0 = ok; else okx1 = ok;
+      if (i == 0 || tid < 128) {   // second round: 128 of the 512 threads
         if (XPACKED) {
-          const char* rec = reinterpret_cast<const char*>(a.x) +
-                            (((size_t)n * (a.Cin / 8) + cib * 8 + oct) * in_plane + (si >= 0 ? si : 0)) * 32;
-          const f32x4 q0 = *reinterpret_cast<const f32x4*>(rec), q1 = *reinterpret_cast<const f32x4*>(rec + 16);
+          const char* recb = reinterpret_cast<const char*>(a.x) +
+                             (((long)n * (a.Cin / 8) + cib * 8 + hf * 4) * (long)in_plane + origin) * 32;
+          const unsigned vo = ((unsigned)octr * (unsigned)in_plane + lin) * 32u;
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(recb + vo);
+          const f32x4 q1 = *reinterpret_cast<const f32x4*>(recb + vo + 16);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { xr[i][j] = q0[j]; xr[i][4 + j] = q1[j]; }
         } else {
+          const float* xn = xb + ((long)n * xch + hf * 32) * (long)in_plane + origin;
+          const unsigned vo = (unsigned)octr * 8u * (unsigned)in_plane + lin;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xr[i][j] = src[(size_t)j * in_plane];
+          for (int j = 0; j < 8; ++j) xr[i][j] = (xn + (size_t)j * in_plane)[vo];
         }
       }
     }
-    vmask = m;
   };
+  // per-thread LDS offsets of the staged tasks (k-step / ci-tile parts are added per half)
+  const int dc0 = (quad >> 3) * 4096 + pixl * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
+  const int dc1 = OFF_D8 + (quad >> 3) * (64 * 32) + pixl * 32 + (quad & 7) * 4;
   auto commit = [&](int buf, int hf) __attribute__((always_inline)) {
     unsigned char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (!((vmask >> i) & 1)) {
+      if (!(i == 0 ? okd0 : okd1)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dyr[i][j] = 0.f;
       }
-      if (!((vmask >> (2 + i)) & 1)) {
+      if (!(i == 0 ? okx0 : okx1)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xr[i][j] = 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pixl = tid & 15, quad = tid >> 4;
       typedef short s16x2 __attribute__((ext_vector_type(2)));
       float v[4], lo[4];
       int hp[2];   // 4 x f16, converted and subtracted with 3.5 VALU instructions per element (see convert_store_x)
@@ -1075,11 +1104,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       int h8v = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
       h8v = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h8v, true);
       const int ks = 2 * hf + i;
-      const int off = (quad >> 3) * 4096 + (ks * 16 + pixl) * 64 + (((quad & 7) ^ ((pixl >> 1) & 7)) * 8);
-      *reinterpret_cast<i32x2*>(base + off) = hi;
-      const int off8 = OFF_D8 + (quad >> 3) * (64 * 32) + (ks * 16 + pixl) * 32 + (quad & 7) * 4;
-      *reinterpret_cast<int*>(base + off8) = __builtin_bit_cast(int, l8v);   // image 0: dyl'
-      *reinterpret_cast<int*>(base + off8 + D8IMG) = h8v;                    // image 1: dyh'
+      *reinterpret_cast<i32x2*>(base + dc0 + ks * 1024) = hi;
+      *reinterpret_cast<int*>(base + dc1 + ks * 512) = __builtin_bit_cast(int, l8v);   // image 0: dyl'
+      *reinterpret_cast<int*>(base + dc1 + ks * 512 + D8IMG) = h8v;                    // image 1: dyh'
       if (do_db) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dbs[j] += dyr[i][j];
@@ -1087,14 +1114,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int tt = tid + i * 512;
-      if (tt < XHALF) {
-        const int t2 = hf * XHALF + tt;
-        const int oct = t2 / NXP, pix = t2 - oct * NXP;
+      int octr, pix, rr, cc;
+      bool active;
+      xgeom(i, octr, pix, rr, cc, active);
+      if (active) {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         i32x4 hi;
         int h0, h1;
-        typedef short s16x2 __attribute__((ext_vector_type(2)));
         s16x2 l0 = {0, 0}, l1 = {0, 0};
         if (XPACKED) {   // the record already holds the three payloads
 #pragma unroll
@@ -1122,9 +1148,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
           h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][4], xr[i][5], 0, false);
           h1 = __builtin_amdgcn_cvt_pk_bf8_f32(xr[i][6], xr[i][7], h1, true);
         }
-        const int off = OFF_X + (oct >> 2) * (NXP * 64) + pix * 64 + (((oct & 3) ^ ((pix >> 1) & 3)) * 16);
+        // ci-tile hf: octet octr of it; 16-byte unit ^ ((pix >> 1) & 3)
+        const int off = OFF_X + hf * (NXP * 64) + pix * 64 + ((octr ^ ((pix >> 1) & 3)) * 16);
         *reinterpret_cast<i32x4*>(base + off) = hi;
-        const int off8 = OFF_X8 + (oct >> 2) * (NXP * 32) + pix * 32 + (oct & 3) * 8;
+        const int off8 = OFF_X8 + hf * (NXP * 32) + pix * 32 + octr * 8;
         i32x2 hv, lv;
         hv[0] = h0; hv[1] = h1;
         lv[0] = __builtin_bit_cast(int, l0); lv[1] = __builtin_bit_cast(int, l1);
@@ -1145,14 +1172,22 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     const int row = ks >> 1, x0 = 16 * (ks & 1);
     const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
     const f16x8 ah = __builtin_bit_cast(f16x8, tr_frag16(ap + sa0, ap + sa1));
+    // first pixel of a tap's k-step window: (row+ky)*40 + x0 + kx = kx (mod 8).  One lane address per kx and
+    // pixel-row half (6 VALU adds per k-step); ky moves it by a whole halo row = an instruction offset.  (Left to
+    // the compiler every tap cost three address instructions: 30 of the k-step's 40 VALU instructions.)
+    const unsigned char* xw = base + OFF_X + cih * (NXP * 64) + (row * XW + x0) * 64;   // uniform
+    const unsigned char* p00 = xw + sx0;
+    const unsigned char* p01 = xw + (sx1 + 64);
+    const unsigned char* p02 = xw + (sx2 + 128);
+    const unsigned char* p10 = xw + (sx4 + 4 * 64);
+    const unsigned char* p11 = xw + (sx5 + 4 * 64 + 64);
+    const unsigned char* p12 = xw + (sx6 + 4 * 64 + 128);
     auto xfrag = [&](int t) __attribute__((always_inline)) {
       int ky, kx;
       tap_yx(t, PY, PX, ky, kx);
-      // first pixel of the k-step window: (row+ky)*40 + x0 + kx = kx (mod 8)
-      const unsigned char* bp = base + OFF_X + cih * (NXP * 64) + ((row + ky) * XW + x0 + kx) * 64;
-      const int o0 = kx == 0 ? sx0 : (kx == 1 ? sx1 : sx2);
-      const int o1 = (kx == 0 ? sx4 : (kx == 1 ? sx5 : sx6)) + 4 * 64;
-      return __builtin_bit_cast(f16x8, tr_frag16(bp + o0, bp + o1));
+      const unsigned char* q0 = kx == 0 ? p00 : (kx == 1 ? p01 : p02);
+      const unsigned char* q1 = kx == 0 ? p10 : (kx == 1 ? p11 : p12);
+      return __builtin_bit_cast(f16x8, tr_frag16(q0 + ky * (XW * 64), q1 + ky * (XW * 64)));
     };
     f16x8 bh = xfrag(0), nh;   // tap 0 is active for every parity
 #pragma unroll
