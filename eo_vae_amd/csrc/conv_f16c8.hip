@@ -1027,11 +1027,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int oxb = ox0 + 16 * i;
       const bool cok = rowok && oxb < a.Wout;                              // uniform
-      const float* sb = dyn + (cok ? rowoff + (unsigned)(PST * oxb) : 0u);  // off-grid: pixel 0 of the image
+      const char* sb = reinterpret_cast<const char*>(dyn + (cok ? rowoff + (unsigned)(PST * oxb) : 0u));  // off-grid: pixel 0
       const bool ok = cok && pixl < a.Wout - oxb;
-      const unsigned vo = dq + (ok ? (unsigned)(PST * pixl) : 0u);
+      const unsigned vo = (dq + (ok ? (unsigned)(PST * pixl) : 0u)) * 4u;   // BYTE offset: scalar base + 32-bit lane offset
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dyr[i][j] = (sb + (size_t)j * out_plane)[vo];
+      for (int j = 0; j < 4; ++j) dyr[i][j] = *reinterpret_cast<const float*>(sb + (size_t)j * out_plane * 4 + vo);
       if (i == 0) okd0 = ok; else okd1 = ok;
     }
     // halo: pixel (rr, cc) of the tile's halo sits at origin + rr * ys + cc * xs of its plane
@@ -1059,10 +1059,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { xr[i][j] = q0[j]; xr[i][4 + j] = q1[j]; }
         } else {
-          const float* xn = xb + ((long)n * xch + hf * 32) * (long)in_plane + origin;
-          const unsigned vo = (unsigned)octr * 8u * (unsigned)in_plane + lin;
+          const char* xn = reinterpret_cast<const char*>(xb + ((long)n * xch + hf * 32) * (long)in_plane + origin);
+          const unsigned vo = ((unsigned)octr * 8u * (unsigned)in_plane + lin) * 4u;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xr[i][j] = (xn + (size_t)j * in_plane)[vo];
+          for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(xn + (size_t)j * in_plane * 4 + vo);
         }
       }
     }
@@ -1072,15 +1072,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   const int dc1 = OFF_D8 + (quad >> 3) * (64 * 32) + pixl * 32 + (quad & 7) * 4;
   auto commit = [&](int buf, int hf) __attribute__((always_inline)) {
     unsigned char* base = smem + buf * BUF;
+    // zero the invalid tasks -- behind a wave-uniform test: interior tiles have none
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (!(i == 0 ? okd0 : okd1)) {
+      const bool bd = !(i == 0 ? okd0 : okd1), bx = !(i == 0 ? okx0 : okx1) && (i == 0 || tid < 128);
+      if (__builtin_amdgcn_ballot_w64(bd) != 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dyr[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) dyr[i][j] = bd ? 0.f : dyr[i][j];
       }
-      if (!(i == 0 ? okx0 : okx1)) {
+      if (__builtin_amdgcn_ballot_w64(bx) != 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xr[i][j] = 0.f;
+        for (int j = 0; j < 8; ++j) xr[i][j] = bx ? 0.f : xr[i][j];
       }
     }
 #pragma unroll
@@ -1107,10 +1109,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       *reinterpret_cast<i32x2*>(base + dc0 + ks * 1024) = hi;
       *reinterpret_cast<int*>(base + dc1 + ks * 512) = __builtin_bit_cast(int, l8v);   // image 0: dyl'
       *reinterpret_cast<int*>(base + dc1 + ks * 512 + D8IMG) = h8v;                    // image 1: dyh'
-      if (do_db) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dbs[j] += dyr[i][j];
-      }
+      for (int j = 0; j < 4; ++j) dbs[j] += dyr[i][j];   // always (a select on do_db cost 8 more instructions); read only if do_db
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
