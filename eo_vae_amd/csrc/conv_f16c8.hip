@@ -806,6 +806,9 @@ __device__ __forceinline__ int wg_src_index(int mode, int oy0, int ox0, int r, i
   return ((unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win)) ? (vy >> 1) * Win + (vx >> 1) : -1;
 }
 
+#ifndef EOVAE_WG_B8DB
+#define EOVAE_WG_B8DB 1
+#endif
 #ifndef EOVAE_WGRAD_BLOCKS
 #define EOVAE_WGRAD_BLOCKS 256
 #endif
@@ -923,6 +926,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   bool okd0 = true, okd1 = true, okx0 = true, okx1 = true;  // validity of the staged tasks (lane masks in SGPRs)
   const int pixl = tid & 15, quad = tid >> 4;
   auto xgeom = [&](int i, int& octr, int& pix, int& rr, int& cc, bool& active) __attribute__((always_inline)) {
+    int tid = threadIdx.x;   // laundered: the handful of shifts below is recomputed per use instead of living in
+    asm volatile("" : "+v"(tid));   // ~10 registers across the MFMA phases (which need them for fragment prefetch)
     if (i == 0) {
       octr = tid >> 7;
       pix = tid & 127;
@@ -1166,42 +1171,61 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     ky = SUBPIX == 1 ? PY + (t >> 1) : (SUBPIX == 2 ? 1 + (t >> 1) : t / 3);
     kx = SUBPIX == 1 ? PX + (t & 1) : (SUBPIX == 2 ? 1 + (t & 1) : t % 3);
   };
-  // f16 main term of one 16-pixel k-step: one A fragment, one B fragment per tap
-  auto compute16_p = [&](const unsigned char* base, int ks, auto parc) __attribute__((always_inline)) {
-    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
-    const int row = ks >> 1, x0 = 16 * (ks & 1);
-    const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
-    const f16x8 ah = __builtin_bit_cast(f16x8, tr_frag16(ap + sa0, ap + sa1));
+  // f16 main term of one 16-pixel k-step: one A fragment, one B fragment per tap.  The A fragment and the first
+  // B fragment of a k-step are requested by the PREVIOUS phase in front of its last MFMA (F16 hand-over), so that a
+  // phase does not open with an exposed LDS latency (10 of them per tile and wave before).
+  struct F16 { f16x8 ah, bh; };
+  auto xptrs = [&](const unsigned char* base, int ks, const unsigned char* (&q)[6]) __attribute__((always_inline)) {
     // first pixel of a tap's k-step window: (row+ky)*40 + x0 + kx = kx (mod 8).  One lane address per kx and
     // pixel-row half (6 VALU adds per k-step); ky moves it by a whole halo row = an instruction offset.  (Left to
     // the compiler every tap cost three address instructions: 30 of the k-step's 40 VALU instructions.)
+    const int row = ks >> 1, x0 = 16 * (ks & 1);
     const unsigned char* xw = base + OFF_X + cih * (NXP * 64) + (row * XW + x0) * 64;   // uniform
-    const unsigned char* p00 = xw + sx0;
-    const unsigned char* p01 = xw + (sx1 + 64);
-    const unsigned char* p02 = xw + (sx2 + 128);
-    const unsigned char* p10 = xw + (sx4 + 4 * 64);
-    const unsigned char* p11 = xw + (sx5 + 4 * 64 + 64);
-    const unsigned char* p12 = xw + (sx6 + 4 * 64 + 128);
+    q[0] = xw + sx0;
+    q[1] = xw + (sx1 + 64);
+    q[2] = xw + (sx2 + 128);
+    q[3] = xw + (sx4 + 4 * 64);
+    q[4] = xw + (sx5 + 4 * 64 + 64);
+    q[5] = xw + (sx6 + 4 * 64 + 128);
+  };
+  auto first16 = [&](const unsigned char* base, int ks, auto parc) __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+    F16 f;
+    const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
+    f.ah = __builtin_bit_cast(f16x8, tr_frag16(ap + sa0, ap + sa1));
+    const unsigned char* q[6];
+    xptrs(base, ks, q);
+    int ky, kx;
+    tap_yx(0, PY, PX, ky, kx);   // tap 0 is active for every parity
+    f.bh = __builtin_bit_cast(f16x8, tr_frag16(q[kx] + ky * (XW * 64), q[3 + kx] + ky * (XW * 64)));
+    return f;
+  };
+  auto compute16_p = [&](const unsigned char* base, int ks, auto parc, F16 f, auto want_next, F16& nxt)
+      __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+    constexpr bool NEXT = decltype(want_next)::value;
+    const unsigned char* q[6];
+    xptrs(base, ks, q);
     auto xfrag = [&](int t) __attribute__((always_inline)) {
       int ky, kx;
       tap_yx(t, PY, PX, ky, kx);
-      const unsigned char* q0 = kx == 0 ? p00 : (kx == 1 ? p01 : p02);
-      const unsigned char* q1 = kx == 0 ? p10 : (kx == 1 ? p11 : p12);
-      return __builtin_bit_cast(f16x8, tr_frag16(q0 + ky * (XW * 64), q1 + ky * (XW * 64)));
+      return __builtin_bit_cast(f16x8, tr_frag16(q[kx] + ky * (XW * 64), q[3 + kx] + ky * (XW * 64)));
     };
-    f16x8 bh = xfrag(0), nh;   // tap 0 is active for every parity
+    const f16x8 ah = f.ah;
+    f16x8 bh = f.bh, nh = f.bh;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (!tap_ok_of(t, PY, PX)) continue;
       int tn = t + 1;
       while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
       if (tn < NT) nh = xfrag(tn);
+      else if (NEXT) nxt = first16(base, ks + 1, parc);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
       bh = nh;
     }
   };
   // both correction terms of one 32-pixel output row: K = 64 = [dyl' | dyh'] . [xh' | xl']
-  auto compute8_p = [&](const unsigned char* base, int row, auto parc) __attribute__((always_inline)) {
+  auto compute8_p = [&](const unsigned char* base, int row, auto parc, F16& nxt) __attribute__((always_inline)) {
     constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
     auto frag8 = [&](const unsigned char* p) __attribute__((always_inline)) {
       using lds2 = __attribute__((address_space(3))) i32x2;
@@ -1218,34 +1242,55 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       tap_yx(t, PY, PX, ky, kx);
       return frag8(base + b8off + ((row + ky) * XW + kx) * 32);
     };
-    // no register double buffering (144 accumulators + 24 staging registers leave room for ONE 8-VGPR B
-    // fragment; the SIMD's partner wave covers the read latency) and a scheduling fence per tap: left alone
-    // the compiler hoists the transposed reads of all nine taps above the first MFMA and spills them
+    // B fragment of the next tap requested before the current tap's MFMA (one fragment ahead, fenced per tap:
+    // -1.5 .. -2.5 % kernel time; single-buffered every scaled MFMA waited a full LDS latency for its fragment).
+    // The fp32-input plain variant has no 8 registers to spare for it (9 spills) and keeps the single buffer.
+    // Left alone the compiler hoists the transposed reads of all nine taps above the first MFMA and spills them.
+    if constexpr (EOVAE_WG_B8DB && (XPACKED || SUBPIX != 0)) {
+      i32x8 b8 = xfrag8(0), nb8 = b8;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (!tap_ok_of(t, PY, PX)) continue;
-      const i32x8 b8 = xfrag8(t);
-      acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 1 /* A: e5m2 */, 1 /* B: e5m2 */, 0,
-                                                                 sc_a, 0, sc_b);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < NT; ++t) {
+        if (!tap_ok_of(t, PY, PX)) continue;
+        int tn = t + 1;
+        while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
+        if (tn < NT) nb8 = xfrag8(tn);
+        else nxt = first16(base, 2 * row, parc);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 1 /* A: e5m2 */, 1 /* B: e5m2 */, 0,
+                                                                   sc_a, 0, sc_b);
+        __builtin_amdgcn_sched_barrier(0);
+        b8 = nb8;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!tap_ok_of(t, PY, PX)) continue;
+        int tn = t + 1;
+        while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
+        const i32x8 b8 = xfrag8(t);
+        if (tn >= NT) nxt = first16(base, 2 * row, parc);
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 1 /* A: e5m2 */, 1 /* B: e5m2 */, 0,
+                                                                   sc_a, 0, sc_b);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
-  auto compute = [&](const unsigned char* base, int ks) __attribute__((always_inline)) {
-    if (!SUBPIX) { compute16_p(base, ks, std::integral_constant<int, 0>{}); return; }
-    switch (par) {  // uniform
-      case 0: compute16_p(base, ks, std::integral_constant<int, 0>{}); break;
-      case 1: compute16_p(base, ks, std::integral_constant<int, 1>{}); break;
-      case 2: compute16_p(base, ks, std::integral_constant<int, 2>{}); break;
-      default: compute16_p(base, ks, std::integral_constant<int, 3>{}); break;
-    }
+  // one output row of the staged tile: its fp8 correction products, then its two f16 k-steps
+  auto compute_row_p = [&](const unsigned char* base, int row, auto parc) __attribute__((always_inline)) {
+    F16 f0, f1, fd;
+    compute8_p(base, row, parc, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute16_p(base, 2 * row, parc, f0, std::true_type{}, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute16_p(base, 2 * row + 1, parc, f1, std::false_type{}, fd);
   };
-  auto compute8 = [&](const unsigned char* base, int row) __attribute__((always_inline)) {
-    if (!SUBPIX) { compute8_p(base, row, std::integral_constant<int, 0>{}); return; }
+  auto compute_row = [&](const unsigned char* base, int row) __attribute__((always_inline)) {
+    if (!SUBPIX) { compute_row_p(base, row, std::integral_constant<int, 0>{}); return; }
     switch (par) {  // uniform
-      case 0: compute8_p(base, row, std::integral_constant<int, 0>{}); break;
-      case 1: compute8_p(base, row, std::integral_constant<int, 1>{}); break;
-      case 2: compute8_p(base, row, std::integral_constant<int, 2>{}); break;
-      default: compute8_p(base, row, std::integral_constant<int, 3>{}); break;
+      case 0: compute_row_p(base, row, std::integral_constant<int, 0>{}); break;
+      case 1: compute_row_p(base, row, std::integral_constant<int, 1>{}); break;
+      case 2: compute_row_p(base, row, std::integral_constant<int, 2>{}); break;
+      default: compute_row_p(base, row, std::integral_constant<int, 3>{}); break;
     }
   };
 
@@ -1280,10 +1325,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         // order.  Staggering the commit between waves 0-3 and 4-7 -- SQ counters show VALU 2 x 23 % and MFMA
         // 38 % of a SIMD's cycles adding up -- spilled 498 in either arrangement tried.)
         __builtin_amdgcn_sched_barrier(0);
-        compute8(base, hf);   // the row's two k-steps share one K = 64 correction product per tap
+        compute_row(base, hf);   // the row's two k-steps share one K = 64 correction product per tap
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-        for (int sub = 0; sub < 2; ++sub) compute(base, 2 * hf + sub);
         if (has_next) commit(cur ^ 1, hf);
       }
       __syncthreads();
