@@ -288,8 +288,9 @@ def main():
             kname = 'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)'
             path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) on v_mfma_f32_32x32x16_f16 + ONE K-concatenated '
                     'block-scaled fp8 product [x_lo|x_hi].[w_hi|w_lo] on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 '
-                    'accumulate (~1e-5 per product; 2 MFMA units per algorithmic product => frac <= 1/2); weight '
-                    'gradients, 1x1 convolutions and attention stay split-bf16 (3 units)')
+                    'accumulate (~1e-5 per product; 2 MFMA units per algorithmic product => frac <= 1/2), forward, data '
+                    'gradient and weight gradient; GroupNorm hands activations over as f16c8 operand records; 1x1 '
+                    'convolutions and attention stay split-bf16 (3 units)')
         else:
             peak = PEAK_BF16_MFMA
             kname = 'conv3x3_bf16_kernel (3x3 conv fwd + data-grad, split-bf16 operands)'
