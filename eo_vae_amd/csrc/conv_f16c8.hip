@@ -520,6 +520,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       rowoff[j] = MSHUFFLE ? (unsigned)((2 * oyc + py) * (2 * a.Wout) + 2 * oxc + px)
                            : (unsigned)(oyc * a.Wout + oxc);
     }
+    // Full tiles address y / residual / bias as  wave-uniform pointer (block + wave channel base, then the channel of
+    // the (i, qq, k) batch entry: scalar ALU)  +  per-lane 32-bit byte offset (the lane half's 4 planes + its pixel).
+    // (Per-lane 64-bit channel * plane products cost ~7 VALU instructions per channel, two of them quarter-rate
+    // multiplies: the epilogue was 640 VALU instructions per wave tile, more than a 128-channel tile has MFMAs.)
+    unsigned lo[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) lo[j] = (unsigned)(((size_t)(4 * h) * out_plane + rowoff[j]) * 4);
+    const unsigned h16 = (unsigned)h * 16u;
+    char* const ywb = reinterpret_cast<char*>(yn + (size_t)(co_blk + wco) * out_plane);
+    const char* const rwb = reinterpret_cast<const char*>(rn + (size_t)(co_blk + wco) * out_plane);
+    const char* const bwb = reinterpret_cast<const char*>(a.bias + (co_blk + wco));
     auto body = [&](auto full_t) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_t)::value;
       // residual requested half a wave tile at a time (4 x 4 x NI loads in flight, one wait): fetched batch by
@@ -527,15 +538,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float rv[4][4][NI];
-        if (rn) {
+        if (!rn) {   // uniform: no residual -> zeros, so that the add below needs no select per value
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int j = 0; j < NI; ++j) rv[qq][k][j] = 0.f;
+        } else {
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const int co = co_base + i * 32 + k + 8 * qq;
-              const int cc = (FULL || co < chans) ? co : chans - 1;
+              if constexpr (FULL) {
+                const char* rp = rwb + (size_t)(i * 32 + 8 * qq + k) * out_plane * 4;   // uniform
 #pragma unroll
-              for (int j = 0; j < NI; ++j) rv[qq][k][j] = rn[(size_t)cc * out_plane + rowoff[j]];
+                for (int j = 0; j < NI; ++j) rv[qq][k][j] = *reinterpret_cast<const float*>(rp + lo[j]);
+              } else {
+                const int co = co_base + i * 32 + k + 8 * qq;
+                const int cc = co < chans ? co : chans - 1;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) rv[qq][k][j] = rn[(size_t)cc * out_plane + rowoff[j]];
+              }
             }
         }
 #pragma unroll
@@ -555,15 +579,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
             const int co = co_base + i * 32 + k + 8 * qq;
             cok[k] = FULL || co < chans;
             coc[k] = cok[k] ? co : chans - 1;
-            bias4[k] = a.bias ? a.bias[coc[k]] : 0.f;
+            if constexpr (FULL)
+              bias4[k] = a.bias ? *reinterpret_cast<const float*>(bwb + (i * 32 + 8 * qq + k) * 4 + h16) : 0.f;
+            else
+              bias4[k] = a.bias ? a.bias[coc[k]] : 0.f;
           }
           float v[4][NI];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-              v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k];
-              if (rn) v[k][j] += rv[qq][k][j];
+              v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k] + rv[qq][k][j];
               if (!FULL) asm volatile("" : "+v"(v[k][j]));
             }
           if (a.gn_sums) {
@@ -594,10 +620,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
             }
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
+          for (int k = 0; k < 4; ++k) {
+            if constexpr (FULL) {
+              char* yp = ywb + (size_t)(i * 32 + 8 * qq + k) * out_plane * 4;   // uniform
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-              if (FULL || (cok[k] && rowok[j])) yn[(size_t)coc[k] * out_plane + rowoff[j]] = v[k][j];
+              for (int j = 0; j < NI; ++j) *reinterpret_cast<float*>(yp + lo[j]) = v[k][j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < NI; ++j)
+                if (cok[k] && rowok[j]) yn[(size_t)coc[k] * out_plane + rowoff[j]] = v[k][j];
+            }
+          }
         }
       }
     };
