@@ -1415,17 +1415,50 @@ __global__ void absmax_bits_kernel(const float* __restrict__ x, size_t n, unsign
   }
 }
 
+// per-block max |x| -> part[blockIdx.x] (plain stores: no zero-filled target, no atomics)
+__global__ void absmax_part_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  float m = 0.f;
+  const size_t n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+  m = wave_max(m);
+  __shared__ float part[16];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, part[i]);
+    partial[blockIdx.x] = (m < 3.0e38f) ? m : 0.f;   // NaN / inf never become the scale
+  }
+}
+
+constexpr int PACK_PARTS = 256;   // amax partials kept behind the header of a packed weight buffer
+
 // w[Cout][Cin][9] fp32 -> per (tap, 32-ch chunk, 128-co block) one 16 KiB tile:
 //   [0, 8 KiB)     f16  [octet 0..3][128 m][8 k]
 //   [8 KiB, 16 KiB) e4m3 [wh' | wl'][half 0..1][128 m][16 k]
 // flip = 0: k = ci, m = co;  flip = 1 (data gradient): k = co, m = ci, taps reversed.
 // One thread = 4 consecutive k of one (tile, m): one dword of each fp8 image, 8 bytes of the f16 image.
 __global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp, int Cout, int Cin,
-                                  int nchunk, int ncob, int flip, float scale, const unsigned* __restrict__ hdr,
-                                  unsigned* __restrict__ hdr_copy) {
-  const unsigned wbits = *hdr;   // amax(|w|) bits of the UNSCALED weights; `scale` is a power of two
-  if (hdr_copy && blockIdx.x == 0 && threadIdx.x == 0) *hdr_copy = wbits;   // second orientation: own header
-  const float amax = __builtin_bit_cast(float, wbits) * fabsf(scale);
+                                  int nchunk, int ncob, int flip, float scale, const float* __restrict__ parts,
+                                  int nparts, unsigned* __restrict__ hdr) {
+  // amax(|w|) of the UNSCALED weights = max of the partial maxima absmax_part_kernel left behind the header
+  // (every block folds the <= 256 numbers itself: no fold launch, no zero-filled atomic target); `scale` is a
+  // power of two.  Block 0 publishes the bits in this buffer's header for the convolution kernel.
+  __shared__ float wmax_s[4];
+  {
+    float m = (int)threadIdx.x < nparts ? parts[threadIdx.x] : 0.f;
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax_s[threadIdx.x >> 6] = m;
+    __syncthreads();
+  }
+  const float wmax = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
+  const unsigned wbits = __builtin_bit_cast(unsigned, wmax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = wbits;
+  const float amax = wmax * fabsf(scale);
   const int e1 = amax > 0.f ? 7 - expo_of_bits(__builtin_bit_cast(unsigned, amax)) : 0;
   const float s_hi = pow2f(e1), s_lo = pow2f(e1 + 12);   // |wl| <= 2^-11 |w|: wl * s_lo stays under 256
   const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
@@ -1491,10 +1524,11 @@ int eovae_absmax_bits(const float* x, size_t n, unsigned* out_bits, void* stream
   return EOVAE_OK;
 }
 
-// bytes of the f16c8-packed weight buffer of a 3x3 layer (tiles + 16-byte header with amax(|w|) bits)
+// bytes of the f16c8-packed weight buffer of a 3x3 layer (tiles + 16-byte header with amax(|w|) bits + scratch for
+// the amax partials of the pack call)
 size_t eovae_conv3x3_f16c8_packed_bytes(int Cout, int Cin, int flip) {
   const int k = flip ? Cout : Cin, m = flip ? Cin : Cout;
-  return (size_t)9 * cdiv(k, 32) * cdiv(m, 128) * 16384 + 16;
+  return (size_t)9 * cdiv(k, 32) * cdiv(m, 128) * 16384 + 16 + PACK_PARTS * sizeof(float);
 }
 
 int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale, void* stream) {
@@ -1503,21 +1537,19 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
   const int nchunk = cdiv(k, 32), ncob = cdiv(m, 128);
   unsigned char* base = (unsigned char*)wp;
   unsigned* hdr = (unsigned*)(base + (size_t)9 * nchunk * ncob * 16384);
+  float* parts = (float*)(hdr + 4);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(hdr, 0, 16, st) != hipSuccess) {
-    eovae_set_error("conv3x3_f16c8_pack: memset failed");
-    return EOVAE_ERR_LAUNCH;
-  }
+  EOVAE_CHECK_ARG(((uintptr_t)w & 15) == 0, "conv3x3_f16c8_pack: w must be 16-byte aligned");
   const size_t nw = (size_t)Cout * Cin * 9;
   size_t ab = (nw / 4 + 255) / 256;
-  if (ab > 1024) ab = 1024;
+  if (ab > PACK_PARTS) ab = PACK_PARTS;
   if (ab < 1) ab = 1;
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)ab), dim3(256), 0, st, w, nw, hdr);
+  hipLaunchKernelGGL(absmax_part_kernel, dim3((unsigned)ab), dim3(256), 0, st, w, nw, parts);
   const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
-                     scale, (const unsigned*)hdr, (unsigned*)nullptr);
+                     scale, (const float*)parts, (int)ab, hdr);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack");
   return EOVAE_OK;
 }
@@ -1534,23 +1566,21 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
   const int nch0 = cdiv(Cin, 32), ncb0 = cdiv(Cout, 128), nch1 = cdiv(Cout, 32), ncb1 = cdiv(Cin, 128);
   unsigned* hdr0 = (unsigned*)(b0 + (size_t)9 * nch0 * ncb0 * 16384);
   unsigned* hdr1 = (unsigned*)(b1 + (size_t)9 * nch1 * ncb1 * 16384);
-  if (hipMemsetAsync(hdr0, 0, 16, st) != hipSuccess) {
-    eovae_set_error("conv3x3_f16c8_pack_pair: memset failed");
-    return EOVAE_ERR_LAUNCH;
-  }
+  EOVAE_CHECK_ARG(((uintptr_t)w & 15) == 0, "conv3x3_f16c8_pack_pair: w must be 16-byte aligned");
+  float* parts = (float*)(hdr0 + 4);
   const size_t nw = (size_t)Cout * Cin * 9;
   size_t ab = (nw / 4 + 255) / 256;
-  if (ab > 1024) ab = 1024;
+  if (ab > PACK_PARTS) ab = PACK_PARTS;
   if (ab < 1) ab = 1;
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)ab), dim3(256), 0, st, w, nw, hdr0);
-  auto launch = [&](unsigned char* base, int nchunk, int ncob, int flip, unsigned* copy) {
+  hipLaunchKernelGGL(absmax_part_kernel, dim3((unsigned)ab), dim3(256), 0, st, w, nw, parts);
+  auto launch = [&](unsigned char* base, int nchunk, int ncob, int flip, unsigned* hdr) {
     const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
-                       scale, (const unsigned*)hdr0, copy);
+                       scale, (const float*)parts, (int)ab, hdr);
   };
-  launch(b0, nch0, ncb0, 0, nullptr);
+  launch(b0, nch0, ncb0, 0, hdr0);
   launch(b1, nch1, ncb1, 1, hdr1);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack_pair");
   return EOVAE_OK;

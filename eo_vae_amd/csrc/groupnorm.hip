@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 __global__ void gn_bwd_finalize_kernel(const double* __restrict__ sums,
                                        const float* __restrict__ gamma, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ gm, int N,
-                                       int C, int cpg, double inv_count) {
+                                       int C, int cpg, double inv_count, unsigned* __restrict__ amax_zero) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && amax_zero) *amax_zero = 0u;   // the fold kernel's atomicMax target (saves a memset launch)
   if (t < C) {
     double a = 0, b = 0;
     for (int n = 0; n < N; ++n) {
@@ -411,12 +412,8 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
                        beta, stats, sums, C, HW, cpg);
   int nt = C > N * G ? C : N * G;
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, st, sums, gamma,
-                     dgamma, dbeta, gm, N, C, cpg, 1.0 / ((double)cpg * HW));
+                     dgamma, dbeta, gm, N, C, cpg, 1.0 / ((double)cpg * HW), dx_amax_bits);
   const int chunks = chunks_for(HW);
-  if (dx_amax_bits && hipMemsetAsync(dx_amax_bits, 0, sizeof(unsigned), st) != hipSuccess) {
-    eovae_set_error("gn_silu_bwd: memset failed");
-    return EOVAE_ERR_LAUNCH;
-  }
   float* part = dx_amax_bits ? gm + (size_t)N * G * 2 : nullptr;
   if (silu)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(N * C * chunks), dim3(256), 0, st, x, dy,
