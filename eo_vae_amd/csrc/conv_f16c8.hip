@@ -839,6 +839,9 @@ __device__ __forceinline__ int wg_src_index(int mode, int oy0, int ox0, int r, i
   return ((unsigned)vy < (unsigned)(2 * Hin) && (unsigned)vx < (unsigned)(2 * Win)) ? (vy >> 1) * Win + (vx >> 1) : -1;
 }
 
+#ifndef EOVAE_WG_LEAN
+#define EOVAE_WG_LEAN 1
+#endif
 #ifndef EOVAE_WG_B8DB
 #define EOVAE_WG_B8DB 1
 #endif
@@ -878,7 +881,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
-  const int ct = wave & 3, cih = wave >> 2;
+  // Wave tile: TWO co-tiles x one ci-tile x HALF of the taps (wave >> 2 selects taps 0..NTA-1 or NTA..NT-1), i.e.
+  // every X fragment read from LDS feeds two MFMAs.  (One co-tile x all nine taps per wave -- the r1 tiling -- read
+  // 40 KB of fragments per 27 MFMAs: 2560 LDS clocks against 2304 MFMA clocks per half tile; now
+  // 26 KB.)  Waves w and w + 4 share a SIMD: one of each tap group, so the 5 / 4 split balances per SIMD.
+  const int tg = __builtin_amdgcn_readfirstlane(wave >> 2), ctp = wave & 1, cih = (wave >> 1) & 1;
+  const int ct = 2 * ctp;   // first of the wave's two co-tiles
   // XCD-aware block -> (slab, tile stride slot) map.  Workgroups are dealt round-robin to the 8 XCDs, each with
   // its own L2.  The slabs (co-block x ci-block) that walk the SAME pixel tiles -- ncib of them share every dY
   // tile, ncob every X tile -- are given consecutive slots of ONE XCD, so a shared tile is fetched into one L2
@@ -933,11 +941,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   }
   const int sc_a = 127 - 12, sc_b = 127;   // E8M0: both K blocks carry one operand scaled by 2^12
 
-  f32x16 acc[NT];
+  constexpr int NTA = (NT + 1) / 2;   // taps of group 0 (5 of 9, 2 of 4); group 1 has NT - NTA
+  f32x16 acc[NTA][2];                // [tap of the wave's group][co-tile]
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NTA; ++t)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
 
   // staging registers: HALF a tile (one output row of 32 pixels + its share of the halo) is issued
   // before two k-steps (54 MFMAs per wave, ~1.7 us per SIMD pair) and committed to the other LDS
@@ -1204,10 +1215,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     ky = SUBPIX == 1 ? PY + (t >> 1) : (SUBPIX == 2 ? 1 + (t >> 1) : t / 3);
     kx = SUBPIX == 1 ? PX + (t & 1) : (SUBPIX == 2 ? 1 + (t & 1) : t % 3);
   };
-  // f16 main term of one 16-pixel k-step: one A fragment, one B fragment per tap.  The A fragment and the first
-  // B fragment of a k-step are requested by the PREVIOUS phase in front of its last MFMA (F16 hand-over), so that a
-  // phase does not open with an exposed LDS latency (10 of them per tile and wave before).
-  struct F16 { f16x8 ah, bh; };
+  // f16 main term of one 16-pixel k-step: two A fragments (the wave's co-tiles), one B fragment per tap of the wave's
+  // group.  The A fragments and the first B fragment of a k-step are requested by the PREVIOUS phase in front of its
+  // last MFMAs (F16 hand-over), so that a phase does not open with an exposed LDS latency.
+  struct F16 { f16x8 ah[2], bh; };
   auto xptrs = [&](const unsigned char* base, int ks, const unsigned char* (&q)[6]) __attribute__((always_inline)) {
     // first pixel of a tap's k-step window: (row+ky)*40 + x0 + kx = kx (mod 8).  One lane address per kx and
     // pixel-row half (6 VALU adds per k-step); ky moves it by a whole halo row = an instruction offset.  (Left to
@@ -1221,21 +1232,27 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     q[4] = xw + (sx5 + 4 * 64 + 64);
     q[5] = xw + (sx6 + 4 * 64 + 128);
   };
-  auto first16 = [&](const unsigned char* base, int ks, auto parc) __attribute__((always_inline)) {
-    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+  // first / one-past-last tap of group TG, and the next active tap at or after t (NT if none)
+  auto next_ok = [&](int t, int t1, int PY, int PX) { while (t < t1 && !tap_ok_of(t, PY, PX)) ++t; return t < t1 ? t : NT; };
+  auto first16 = [&](const unsigned char* base, int ks, auto parc, auto tgc) __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1, TG = decltype(tgc)::value;
+    constexpr int T0 = TG ? NTA : 0, T1 = TG ? NT : NTA;
     F16 f;
     const unsigned char* ap = base + ct * 4096 + ks * 16 * 64;
-    f.ah = __builtin_bit_cast(f16x8, tr_frag16(ap + sa0, ap + sa1));
+    f.ah[0] = __builtin_bit_cast(f16x8, tr_frag16(ap + sa0, ap + sa1));
+    f.ah[1] = __builtin_bit_cast(f16x8, tr_frag16(ap + 4096 + sa0, ap + 4096 + sa1));
     const unsigned char* q[6];
     xptrs(base, ks, q);
-    int ky, kx;
-    tap_yx(0, PY, PX, ky, kx);   // tap 0 is active for every parity
+    const int tf = next_ok(T0, T1, PY, PX);
+    int ky = 0, kx = 0;
+    if (tf < NT) tap_yx(tf, PY, PX, ky, kx);
     f.bh = __builtin_bit_cast(f16x8, tr_frag16(q[kx] + ky * (XW * 64), q[3 + kx] + ky * (XW * 64)));
     return f;
   };
-  auto compute16_p = [&](const unsigned char* base, int ks, auto parc, F16 f, auto want_next, F16& nxt)
+  auto compute16_p = [&](const unsigned char* base, int ks, auto parc, auto tgc, F16 f, auto want_next, F16& nxt)
       __attribute__((always_inline)) {
-    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1, TG = decltype(tgc)::value;
+    constexpr int T0 = TG ? NTA : 0, T1 = TG ? NT : NTA;
     constexpr bool NEXT = decltype(want_next)::value;
     const unsigned char* q[6];
     xptrs(base, ks, q);
@@ -1244,22 +1261,22 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       tap_yx(t, PY, PX, ky, kx);
       return __builtin_bit_cast(f16x8, tr_frag16(q[kx] + ky * (XW * 64), q[3 + kx] + ky * (XW * 64)));
     };
-    const f16x8 ah = f.ah;
     f16x8 bh = f.bh, nh = f.bh;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = T0; t < T1; ++t) {
       if (!tap_ok_of(t, PY, PX)) continue;
-      int tn = t + 1;
-      while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
+      const int tn = next_ok(t + 1, T1, PY, PX);
       if (tn < NT) nh = xfrag(tn);
-      else if (NEXT) nxt = first16(base, ks + 1, parc);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+      else if (NEXT) nxt = first16(base, ks + 1, parc, tgc);
+      acc[t - T0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[0], bh, acc[t - T0][0], 0, 0, 0);
+      acc[t - T0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[1], bh, acc[t - T0][1], 0, 0, 0);
       bh = nh;
     }
   };
   // both correction terms of one 32-pixel output row: K = 64 = [dyl' | dyh'] . [xh' | xl']
-  auto compute8_p = [&](const unsigned char* base, int row, auto parc, F16& nxt) __attribute__((always_inline)) {
-    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1;
+  auto compute8_p = [&](const unsigned char* base, int row, auto parc, auto tgc, F16& nxt) __attribute__((always_inline)) {
+    constexpr int PARC = decltype(parc)::value, PY = (PARC >> 1) & 1, PX = PARC & 1, TG = decltype(tgc)::value;
+    constexpr int T0 = TG ? NTA : 0, T1 = TG ? NT : NTA;
     auto frag8 = [&](const unsigned char* p) __attribute__((always_inline)) {
       using lds2 = __attribute__((address_space(3))) i32x2;
       const i32x2 v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p));
@@ -1269,68 +1286,81 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       const i32x4 lo = __builtin_shufflevector(v0, v1, 0, 1, 2, 3), hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3);
       return (i32x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    const i32x8 a8 = frag8(base + a8off + row * (32 * 32));
+    const i32x8 a80 = frag8(base + a8off + row * (32 * 32));
+    const i32x8 a81 = frag8(base + a8off + (64 * 32) + row * (32 * 32));
     auto xfrag8 = [&](int t) __attribute__((always_inline)) {
       int ky, kx;
       tap_yx(t, PY, PX, ky, kx);
       return frag8(base + b8off + ((row + ky) * XW + kx) * 32);
     };
-    // B fragment of the next tap requested before the current tap's MFMA (one fragment ahead, fenced per tap:
-    // -1.5 .. -2.5 % kernel time; single-buffered every scaled MFMA waited a full LDS latency for its fragment).
-    // The fp32-input plain variant has no 8 registers to spare for it (9 spills) and keeps the single buffer.
-    // Left alone the compiler hoists the transposed reads of all nine taps above the first MFMA and spills them.
-    if constexpr (EOVAE_WG_B8DB && (XPACKED || SUBPIX != 0)) {
-      i32x8 b8 = xfrag8(0), nb8 = b8;
+    // B fragment of the next tap requested before the current tap's MFMAs (one fragment ahead, fenced per tap;
+    // left alone the compiler hoists the transposed reads of all taps above the first MFMA and spills them).
+    const int tf = next_ok(T0, T1, PY, PX);
+    if (tf >= NT) { nxt = first16(base, 2 * row, parc, tgc); return; }
+    if constexpr (EOVAE_WG_LEAN == 1 && SUBPIX == 0) {
+      // plain 3x3: 160 accumulator registers leave no room for a second B fragment: single buffer (each pair of
+      // MFMAs behind its fragment; the SIMD's partner wave covers the read latency)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = T0; t < T1; ++t) {
         if (!tap_ok_of(t, PY, PX)) continue;
-        int tn = t + 1;
-        while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
-        if (tn < NT) nb8 = xfrag8(tn);
-        else nxt = first16(base, 2 * row, parc);
+        const i32x8 b8 = xfrag8(t);
+        acc[t - T0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a80, b8, acc[t - T0][0], 1 /* A: e5m2 */,
+                                                                         1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
+        acc[t - T0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a81, b8, acc[t - T0][1], 1, 1, 0, sc_a, 0, sc_b);
         __builtin_amdgcn_sched_barrier(0);
-        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 1 /* A: e5m2 */, 1 /* B: e5m2 */, 0,
-                                                                   sc_a, 0, sc_b);
-        __builtin_amdgcn_sched_barrier(0);
-        b8 = nb8;
       }
     } else {
+      i32x8 b8 = xfrag8(tf), nb8 = b8;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = T0; t < T1; ++t) {
         if (!tap_ok_of(t, PY, PX)) continue;
-        int tn = t + 1;
-        while (tn < NT && !tap_ok_of(tn, PY, PX)) ++tn;
-        const i32x8 b8 = xfrag8(t);
-        if (tn >= NT) nxt = first16(base, 2 * row, parc);
-        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 1 /* A: e5m2 */, 1 /* B: e5m2 */, 0,
-                                                                   sc_a, 0, sc_b);
+        const int tn = next_ok(t + 1, T1, PY, PX);
+        if (tn < NT) nb8 = xfrag8(tn);
+        else if (!(EOVAE_WG_LEAN && SUBPIX == 0)) nxt = first16(base, 2 * row, parc, tgc);
         __builtin_amdgcn_sched_barrier(0);
+        acc[t - T0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a80, b8, acc[t - T0][0], 1 /* A: e5m2 */,
+                                                                         1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
+        acc[t - T0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a81, b8, acc[t - T0][1], 1, 1, 0, sc_a, 0, sc_b);
+        __builtin_amdgcn_sched_barrier(0);
+        b8 = nb8;
       }
     }
   };
   // one output row of the staged tile: its fp8 correction products, then its two f16 k-steps
-  auto compute_row_p = [&](const unsigned char* base, int row, auto parc) __attribute__((always_inline)) {
+  auto compute_row_p = [&](const unsigned char* base, int row, auto parc, auto tgc) __attribute__((always_inline)) {
     F16 f0, f1, fd;
-    compute8_p(base, row, parc, f0);
-    __builtin_amdgcn_sched_barrier(0);
-    compute16_p(base, 2 * row, parc, f0, std::true_type{}, f1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute16_p(base, 2 * row + 1, parc, f1, std::false_type{}, fd);
+    if constexpr (EOVAE_WG_LEAN && SUBPIX == 0) {   // no register room for the hand-over: every phase requests its own
+      compute8_p(base, row, parc, tgc, fd);
+      __builtin_amdgcn_sched_barrier(0);
+      f0 = first16(base, 2 * row, parc, tgc);
+      compute16_p(base, 2 * row, parc, tgc, f0, std::false_type{}, fd);
+      __builtin_amdgcn_sched_barrier(0);
+      f1 = first16(base, 2 * row + 1, parc, tgc);
+      compute16_p(base, 2 * row + 1, parc, tgc, f1, std::false_type{}, fd);
+    } else {
+      compute8_p(base, row, parc, tgc, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute16_p(base, 2 * row, parc, tgc, f0, std::true_type{}, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute16_p(base, 2 * row + 1, parc, tgc, f1, std::false_type{}, fd);
+    }
   };
-  auto compute_row = [&](const unsigned char* base, int row) __attribute__((always_inline)) {
-    if (!SUBPIX) { compute_row_p(base, row, std::integral_constant<int, 0>{}); return; }
+  auto compute_row_g = [&](const unsigned char* base, int row, auto tgc) __attribute__((always_inline)) {
+    if (!SUBPIX) { compute_row_p(base, row, std::integral_constant<int, 0>{}, tgc); return; }
     switch (par) {  // uniform
-      case 0: compute_row_p(base, row, std::integral_constant<int, 0>{}); break;
-      case 1: compute_row_p(base, row, std::integral_constant<int, 1>{}); break;
-      case 2: compute_row_p(base, row, std::integral_constant<int, 2>{}); break;
-      default: compute_row_p(base, row, std::integral_constant<int, 3>{}); break;
+      case 0: compute_row_p(base, row, std::integral_constant<int, 0>{}, tgc); break;
+      case 1: compute_row_p(base, row, std::integral_constant<int, 1>{}, tgc); break;
+      case 2: compute_row_p(base, row, std::integral_constant<int, 2>{}, tgc); break;
+      default: compute_row_p(base, row, std::integral_constant<int, 3>{}, tgc); break;
     }
   };
 
   // The tile loop is instantiated once per load path: a run-time choice between issue_fast() and
   // issue() inside ONE loop makes the loaded registers phi nodes, and the compiler then waits for
   // vmcnt(0) and copies them at the join -- right after issuing the loads, before the MFMAs.
-  auto run = [&](auto full_t) __attribute__((always_inline)) {
+  // ... and once per tap group: a choice inside the loop would merge the two groups' accumulator updates in phi nodes
+  // (535 spilled registers).
+  auto run = [&](auto full_t, auto tgc) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_t)::value;
     auto load = [&](int tile, int hf) __attribute__((always_inline)) {
       if constexpr (FULL) issue_fast(tile, hf); else issue(tile, hf);
@@ -1358,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         // order.  Staggering the commit between waves 0-3 and 4-7 -- SQ counters show VALU 2 x 23 % and MFMA
         // 38 % of a SIMD's cycles adding up -- spilled 498 in either arrangement tried.)
         __builtin_amdgcn_sched_barrier(0);
-        compute_row(base, hf);   // the row's two k-steps share one K = 64 correction product per tap
+        compute_row_g(base, hf, tgc);   // the row's two k-steps share one K = 64 correction product per tap
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) commit(cur ^ 1, hf);
       }
@@ -1366,7 +1396,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       cur ^= 1;
     }
   };
-  if (fullc) run(std::true_type{}); else run(std::false_type{});
+  if (tg == 0) {   // wave-uniform
+    if (fullc) run(std::true_type{}, std::integral_constant<int, 0>{}); else run(std::false_type{}, std::integral_constant<int, 0>{});
+  } else {
+    if (fullc) run(std::true_type{}, std::integral_constant<int, 1>{}); else run(std::false_type{}, std::integral_constant<int, 1>{});
+  }
 
   if (do_db) {  // lanes 16q..16q+15 hold the same 4 channels at 16 different pixels
 #pragma unroll
@@ -1381,15 +1415,19 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   const int ci = cib * 64 + cih * 32 + r;
   if (ci < a.Cin) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int tl = 0; tl < NTA; ++tl) {
+      const int t = tg ? NTA + tl : tl;   // uniform
+      if (t >= NT) continue;
       const int tap = SUBPIX == 1 ? (py + (t >> 1)) * 3 + px + (t & 1)
                                   : (SUBPIX == 2 ? (1 + (t >> 1)) * 3 + 1 + (t & 1) : t);
       if (SUBPIX == 2 && (((t >> 1) && py) || ((t & 1) && px))) continue;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int co = cob * 128 + ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (co < a.Cout) atomicAdd(&a.dwp[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[t][q] * dyinv);
-      }
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int co = cob * 128 + (ct + c) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (co < a.Cout) atomicAdd(&a.dwp[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[tl][c][q] * dyinv);
+        }
     }
   }
 }
