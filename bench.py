@@ -78,6 +78,20 @@ def pmc_traffic(kernel):
     return None, {'file': None, 'note': 'no PMC fold for this kernel under profiles/'}
 
 
+def wgrad_roofline(wtimer, peak, elapsed, prec):
+    """Second-largest kernel family of the step (the 3x3 weight gradients), measured the same way as `roofline`:
+    algorithmic flops of every launch / HIP-event time around it on the launch stream."""
+    ms, flops, n = wtimer.totals()
+    if n == 0 or ms <= 0:
+        return None
+    kernel = {'f16c8': 'wgrad3x3_f16c8_kernel', 'f32': 'conv_wgrad_kernel'}.get(prec, 'wgrad3x3_bf16_kernel')
+    ach = flops / (ms * 1e-3)
+    return {'bound': 'mfma', 'kernel': kernel + ' (3x3 weight gradient incl. sub-pixel / space-to-depth forms)',
+            'achieved': round(ach / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'launches': n, 'achieved_per_launch_ms': round(ms / n, 4),
+            'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
+
+
 def build_model(channels, kl_weight=1e-6, msssim=False):
     from eo_vae_amd.autoencoder import EOFluxVAE
     from eo_vae_amd.losses import EOConsistencyLoss
@@ -252,6 +266,7 @@ def main():
     if args.workload == 'cfg4':
         batches.base = args.warmup
     ops.CONV3X3_TIMER = ops.KernelTimer()
+    ops.WGRAD3X3_TIMER = ops.KernelTimer()
     # per-step HIP events on the compute stream (SURVEY 8d timing protocol: median and p10/p90
     # beside the barrier-bracketed wall time that `value` is computed from)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -265,6 +280,7 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pick = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]  # noqa: E731
     timer, ops.CONV3X3_TIMER = ops.CONV3X3_TIMER, None
+    wtimer, ops.WGRAD3X3_TIMER = ops.WGRAD3X3_TIMER, None
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -322,6 +338,7 @@ def main():
                          'algorithmic_bytes_per_launch': round(timer.bytes_total() / max(k_n, 1)),
                          'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
+            'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),
             'step_ms_events': {'median': round(pick(0.5), 3), 'p10': round(pick(0.1), 3), 'p90': round(pick(0.9), 3)},
             'step_flops_tflops': round(f_img * ips / world / 1e12, 2),
             'hbm_roofline_frac': round(ips / world / r_hbm, 4),

@@ -83,6 +83,7 @@ class KernelTimer:
 
 
 CONV3X3_TIMER: KernelTimer | None = None  # set by bench.py during the timed region
+WGRAD3X3_TIMER: KernelTimer | None = None  # same for the 3x3 weight-gradient launches (second roofline object)
 
 
 def conv_raw(x, wp, kp, mp, bias, residual, cout, ks, mode, out_scale=1.0):
@@ -252,8 +253,15 @@ def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode
 def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False):
     """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16."""
     lib = L.load()
+    amax = amax_of(dy) if CONV_PRECISION == 'f16c8' else None
+    timed = WGRAD3X3_TIMER is not None
+    if timed:
+        # algorithmic flops of the layer as the reference executes it: 9 taps on the layer's output grid
+        # (subpix 2 = the stride-2 layer: its output grid is the low-res one)
+        ev0, ev1 = WGRAD3X3_TIMER.bracket(2.0 * n * ho * wo * cout * cin * 9, 4.0 * (x.numel() + dy.numel()))
+        ev0.record()
     if CONV_PRECISION == 'f16c8':
-        L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax_of(dy)), n,
+        L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), n,
                                               cin, h, w, cout, ho, wo, mode, subpix, int(packed), L.stream()),
                 'eovae_conv3x3_f16c8_wgrad')
     elif packed:
@@ -262,6 +270,8 @@ def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, p
         L.check(lib.eovae_conv3x3_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), n, cin, h, w, cout, ho,
                                              wo, mode, _PREC[CONV_PRECISION], subpix, L.stream()),
                 'eovae_conv3x3_bf16_wgrad')
+    if timed:
+        ev1.record()
 
 
 def pack_pair_f16c8(weight):

@@ -33,3 +33,6 @@ def test_bench_json_contract():
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert r['traffic'] is None or r['traffic'] > 0
     assert 'traffic_source' in r and (r['traffic'] is None or not r['traffic_source'].get('stale'))
+    w = d['roofline_wgrad']      # second kernel family (3x3 weight gradients), same measurement
+    assert w['bound'] == 'mfma' and 0 < w['frac'] < 1 and abs(w['frac'] - w['achieved'] / w['peak']) < 1e-3
+    assert w['launches'] > 0 and 0 < w['kernel_time_share'] < 1
