@@ -71,7 +71,9 @@ int eovae_conv3x3_bf16_fwd(const float* x, const void* wp, const float* bias, co
  * Replaces the same reference call sites as eovae_conv3x3_bf16_fwd (layers.py:29-50, 70-110 via F.conv2d /
  * its autograd data gradient).  Modes / subpix as eovae_conv3x3_bf16_fwd; the GEMM K channel count must be
  * a multiple of 32.  Weights: 16 KiB per (tap, 32-channel chunk, 128-co block) + a 16-byte header holding the
- * float bits of max|w| (set by the packer, read by the kernel for the fp8 block scales).
+ * float bits of max|w| (set by the packer, read by the kernel for the fp8 block scales) + 1 KiB of scratch for the
+ * packer's partial maxima (no memset / fold launches); w must be 16-byte aligned; always size the buffer with
+ * eovae_conv3x3_f16c8_packed_bytes().
  * xamax (nullable): device pointer to the float bits of max|x| (eovae_absmax_bits) for inputs that may sit
  * outside f16's range (gradients): the loader pre-scales by an exact power of two, the epilogue undoes it. */
 int eovae_absmax_bits(const float* x, size_t n, unsigned* out_bits, void* stream);
