@@ -43,6 +43,19 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b'kernel size 5' in lib.eovae_last_error()
     with pytest.raises(L.EovaeError):
         L.check(-1, 'probe')
+    # round-2 arguments of the f16c8 entries are validated before anything touches the device (fake pointers)
+    fp = ctypes.c_void_p(4096)
+    conv = lambda cout, subpix, xpacked, xamax, sums, groups: lib.eovae_conv3x3_f16c8_fwd(  # noqa: E731
+        fp, fp, None, None, fp, xamax, 1, 64, 8, 8, cout, 8, 8, 0, subpix, xpacked, sums, groups, None)
+    assert conv(96, 0, 0, None, fp, 32) != 0 and b'gn_sums needs' in lib.eovae_last_error()      # 3 channels per group
+    assert conv(128, 0, 0, None, fp, 0) != 0 and b'gn_sums needs' in lib.eovae_last_error()
+    assert conv(128, 0, 1, fp, None, 0) != 0 and b'packed input' in lib.eovae_last_error()        # records + pre-scale
+    assert conv(128, 1, 1, None, None, 0) != 0 and b'packed input' in lib.eovae_last_error()      # records in a sub-pixel form
+    assert lib.eovae_conv3x3_f16c8_fwd(fp, fp, None, None, fp, None, 1, 48, 8, 8, 128, 8, 8, 0, 0, 0, None, 0,
+                                       None) != 0 and b'multiple of 32' in lib.eovae_last_error()
+    assert lib.eovae_conv3x3_f16c8_wgrad(fp, fp, fp, None, None, 1, 96, 8, 8, 128, 8, 8, 0, 0, 1, None) != 0   # records need Cin % 64
+    assert lib.eovae_gn_silu_fwd_packed(fp, fp, fp, fp, fp, None, 1, 100, 64, 25, 1e-6, 1, fp, None) != 0 \
+        and b'gn_silu_fwd_packed' in lib.eovae_last_error()                                          # C % 8
 
 
 def test_product_fails_loudly_on_cpu():
