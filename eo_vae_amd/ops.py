@@ -215,7 +215,9 @@ def amax_of(t):
     tag = getattr(t, '_eovae_amax', None)
     if tag is not None and tag[1] == t._version and tag[0].device == t.device:
         return tag[0]
-    return absmax_bits(t)
+    bits = absmax_bits(t)
+    _tag_amax(t, bits)     # the data gradient and the weight gradient of one layer ask for the same tensor
+    return bits
 
 
 def _pack3x3(w4, rows, cols, flip, f16c8):
