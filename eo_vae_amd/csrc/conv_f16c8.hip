@@ -966,7 +966,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
   // and everything that depends on the tile only is wave-uniform (scalar base pointers, 32-bit lane offsets).
   float dyr[2][4], xr[2][8];
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};  // bias-gradient partials of this thread's 4 channels
-  const bool do_db = a.db != nullptr && cib == 0 && SUBPIX != 1;
+  const bool do_db = a.db != nullptr && cib == 0;   // sub-pixel form: the four parity blocks of a channel each add their pixels
   bool okd0 = true, okd1 = true, okx0 = true, okx1 = true;  // validity of the staged tasks (lane masks in SGPRs)
   const int pixl = tid & 15, quad = tid >> 4;
   auto xgeom = [&](int i, int& octr, int& pix, int& rr, int& cc, bool& active) __attribute__((always_inline)) {
@@ -1408,8 +1408,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       float v = dbs[j];
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      const int co = cob * 128 + (tid >> 4) * 4 + j;
-      if ((tid & 15) == 0 && co < a.Cout) atomicAdd(&a.db[co], v);
+      const int co = cob * 128 + (tid >> 4) * 4 + j - (SUBPIX == 1 ? par * a.creal : 0);   // channel of the stored dy
+      if ((tid & 15) == 0 && co < (SUBPIX == 1 ? a.creal : a.Cout)) atomicAdd(&a.db[co], v);
     }
   }
   const int ci = cib * 64 + cih * 32 + r;
@@ -1726,7 +1726,6 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
                               int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
                               int xpacked, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_f16c8_wgrad: null pointer");
-  EOVAE_CHECK_ARG(!(db && subpix == 1), "conv3x3_f16c8_wgrad: db is not produced in subpix 1");
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_f16c8_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_f16c8_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && mode == MODE_NORMAL && Cin % 64 == 0),

@@ -424,12 +424,13 @@ def up_conv_subpix_dgrad(dy, weight, h, w):
     return dx
 
 
-def up_conv_subpix_wgrad(x, dy, weight):
+def up_conv_subpix_wgrad(x, dy, weight, db=None):
+    """db (f16c8 mode only, pre-zeroed [Cout]): the bias gradient rides on the dy tiles the kernel stages."""
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * 4 * cout * cin, dtype=torch.float32, device=x.device)
-    _launch_wgrad3x3(x, dy, dwp, None, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1)
+    _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1)
     dw = torch.empty_like(weight)
     L.check(lib.eovae_subpix_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_subpix_fold')
     return dw
@@ -563,7 +564,9 @@ class Conv2dFn(torch.autograd.Function):
                 L.check(lib.eovae_upsample2x_bwd(L.ptr(du), L.ptr(dx), n, cin, h, w, L.stream()),
                         'eovae_upsample2x_bwd')
         if ctx.needs_input_grad[1] and subpix:
-            dw = up_conv_subpix_wgrad(x, dy, weight)
+            if want_db and CONV_PRECISION == 'f16c8':
+                db = torch.zeros(cout, dtype=torch.float32, device=x.device)
+            dw = up_conv_subpix_wgrad(x, dy, weight, db)
         elif ctx.needs_input_grad[1] and s2d:
             if want_db:
                 db = torch.zeros(cout, dtype=torch.float32, device=x.device)

@@ -94,7 +94,8 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
  * a second time.  Cout / gn_groups must be a power of two in 4..128. */
 /* f16c8 weight gradient (same tiling and sub-pixel forms as eovae_conv3x3_bf16_wgrad; replaces the same
  * autograd call site of F.conv2d, layers.py:29-50, 70-110): per 32 pixels and tap 2 f16 MFMAs + 1 block-scaled
- * fp8 MFMA [dy_lo|dy_hi].[x_hi|x_lo].  dyamax as for the data gradient (NULL = dy used unscaled). */
+ * fp8 MFMA [dy_lo|dy_hi].[x_hi|x_lo].  dyamax as for the data gradient (NULL = dy used unscaled).  db (nullable,
+ * pre-zeroed [Cout]) receives sum(dy) in every form, the sub-pixel one included. */
 int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db,
                               const unsigned* dyamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
                               int Wout, int mode, int subpix, int xpacked, void* stream);
