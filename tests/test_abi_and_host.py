@@ -247,3 +247,23 @@ model:
     monkeypatch.setattr(builtins, '__import__', no_hub)
     with pytest.raises(ImportError, match='huggingface_hub'):
         EOFluxVAE.from_pretrained('nilsleh/eo-vae')
+
+
+def test_bench_quotes_hbm_traffic_only_for_the_measured_build_and_mode(monkeypatch):
+    """roofline.traffic comes from a committed PMC fold; it must turn into null -- with the reason -- when the kernel
+    sources or the arithmetic mode differ from what the fold was measured on."""
+    import bench
+    from eo_vae_amd import ops
+    val, src = bench.pmc_traffic('conv3x3_f16c8_kernel')
+    assert src['file'] and src['file'].startswith('profiles/r')
+    if val is not None:                                   # fold of this very source tree
+        assert src['csrc_digest'] == bench.csrc_digest() and 'stale' not in src and val > 0
+    else:
+        assert 'stale' in src
+    monkeypatch.setattr(ops, 'CONV_PRECISION', 'bf16')
+    val2, src2 = bench.pmc_traffic('conv3x3_bf16_kernel')
+    assert val2 is None and 'conv precision' in src2['stale']
+    monkeypatch.setattr(bench, 'csrc_digest', lambda: 'deadbeefdeadbeef')
+    monkeypatch.setattr(ops, 'CONV_PRECISION', ops.DEFAULT_PRECISION)
+    val3, src3 = bench.pmc_traffic('conv3x3_f16c8_kernel')
+    assert val3 is None and 'kernel sources changed' in src3['stale']
