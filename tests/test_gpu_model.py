@@ -174,4 +174,19 @@ def test_full_size_kernel_properties():
         shift = torch.randn(B, 32, 1, 1, 1, device='cuda')
         x3 = (x1.view(B, 32, C // 32, H, H) * scale + shift).view(B, C, H, H)
         assert rel(ops.group_norm_silu(x3, gamma, beta), z1) < 2e-4      # eps 1e-6 and fp32 statistics
+        if ops.CONV_PRECISION == 'f16c8':
+            # round 2: the forward pair GroupNorm -> records -> conv (+ residual) -> GroupNorm sums from its epilogue
+            a = ops.group_norm_silu(x1, gamma, beta, packed=True)        # operand records
+            assert ops.is_packed(a)
+            yb_ = ops.conv2d(a, w.detach(), b.detach(), x2, 'normal')    # x2 as the residual
+            sums = ops.gn_sums_of(yb_, 32)
+            assert sums is not None
+            yd = yb_.double().view(B, 32, -1)
+            want = torch.stack([yd.sum(-1), (yd * yd).sum(-1)], -1)
+            assert (sums - want).abs().max() <= 2e-6 * want.abs().max()  # checksum of the 0.5-GB tensor per group
+            # records carry what fp32 carries: same conv result from the fp32 hand-over up to the operand rounding
+            y_ref = ops.conv2d(z1, w.detach(), b.detach(), x2, 'normal')
+            assert rel(yb_, y_ref) < 2e-5
+            # and the GroupNorm that consumes the tag equals one that measures the tensor itself
+            assert rel(ops.group_norm_silu(yb_, gamma, beta), ops.group_norm_silu(yb_.clone(), gamma, beta)) < 2e-6
     torch.cuda.synchronize()
