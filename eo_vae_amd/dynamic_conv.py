@@ -38,6 +38,40 @@ class FCResLayer(nn.Module):  # :336-366
         return x + F.relu(self.w2(F.relu(self.w1(x))))
 
 
+# The encoder's hyper-network is the head (forward, before conv_in) and the tail (backward, after the last weight
+# gradient) of every train step: ~110 + ~190 five-microsecond launches = 3.6 ms that nothing can overlap (DESIGN.md
+# s7).  `nn.TransformerEncoderLayer` + the MATH SDPA path spend ~24 launches per layer on reshapes, scalings and
+# copies; the same post-norm layer written out on the same parameters needs 13 (one in_proj GEMM, a scaled
+# batched QK^T, softmax, PV, one head-merge copy, out_proj, add, LayerNorm, FFN GEMM + GELU + GEMM, add, LayerNorm).
+FAST_GENERATOR = os.environ.get('EOVAE_FAST_GENERATOR', '1') != '0'
+
+
+def _encoder_layer(layer, x):
+    """nn.TransformerEncoderLayer.forward for an unbatched [L, d] input, post-norm, exact GELU, dropout 0
+    (the configuration of dynamic_conv.py:86-101), on the layer's own parameters."""
+    att = layer.self_attn
+    seq_len, d = x.shape
+    h = att.num_heads
+    dh = d // h
+    qkv = F.linear(x, att.in_proj_weight, att.in_proj_bias).view(seq_len, 3, h, dh)
+    q, k, v = (qkv[:, i].transpose(0, 1) for i in range(3))                  # [h, L, dh] strided views
+    s = torch.baddbmm(torch.empty(h, seq_len, seq_len, dtype=x.dtype, device=x.device), q, k.transpose(1, 2),
+                      beta=0.0, alpha=float(dh) ** -0.5)
+    o = torch.bmm(torch.softmax(s, dim=-1), v).transpose(0, 1).reshape(seq_len, d)
+    x = F.layer_norm(x + F.linear(o, att.out_proj.weight, att.out_proj.bias), (d,), layer.norm1.weight,
+                     layer.norm1.bias, layer.norm1.eps)
+    f = F.linear(F.gelu(F.linear(x, layer.linear1.weight, layer.linear1.bias)), layer.linear2.weight,
+                 layer.linear2.bias)
+    return F.layer_norm(x + f, (d,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+
+
+def _layer_is_plain(layer):
+    return (isinstance(layer, nn.TransformerEncoderLayer) and not layer.norm_first
+            and layer.activation_relu_or_gelu == 2 and layer.dropout.p == 0.0 and layer.dropout1.p == 0.0
+            and layer.dropout2.p == 0.0 and layer.self_attn._qkv_same_embed_dim and layer.self_attn.bias_k is None
+            and not layer.self_attn.add_zero_attn)
+
+
 class TransformerWeightGenerator(nn.Module):  # :62-130
     _bias_out = None  # encoder flavour: one bias vector of embed_dim
 
@@ -57,7 +91,12 @@ class TransformerWeightGenerator(nn.Module):  # :62-130
 
     def _tokens(self, waves):
         seq = torch.cat([self.weight_tokens, waves, self.bias_token], dim=0)
-        return self.transformer_encoder(seq)  # unbatched [L, d]
+        enc = self.transformer_encoder
+        if FAST_GENERATOR and enc.norm is None and all(_layer_is_plain(lyr) for lyr in enc.layers):
+            for lyr in enc.layers:
+                seq = _encoder_layer(lyr, seq)
+            return seq
+        return enc(seq)  # unbatched [L, d]
 
     def forward(self, waves):
         out = self._tokens(waves)
