@@ -45,6 +45,20 @@ class FCResLayer(nn.Module):  # :336-366
 # batched QK^T, softmax, PV, one head-merge copy, out_proj, add, LayerNorm, FFN GEMM + GELU + GEMM, add, LayerNorm).
 FAST_GENERATOR = os.environ.get('EOVAE_FAST_GENERATOR', '1') != '0'
 
+# The hyper-network's GEMMs are 132-row problems ([132, 256] x [256, 256 .. 2048]).  PyTorch-ROCm's default BLAS
+# (hipBLASLt) picks 256-row macro tiles for them: 19-40 us per call where rocBLAS needs 7-10 (tools/gen_kernels.py).
+# The process-wide preference is switched to rocBLAS here -- every other GEMM of the product runs on its own HIP
+# kernels, so nothing else is affected; EOVAE_GENERATOR_BLAS=keep leaves PyTorch's choice alone.
+if os.environ.get('EOVAE_GENERATOR_BLAS', 'rocblas') == 'rocblas':
+    os.environ.setdefault('DISABLE_ADDMM_CUDA_LT', '1')       # addmm + bias would still go to hipBLASLt
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            torch.backends.cuda.preferred_blas_library('cublas')   # = rocBLAS on ROCm
+    except Exception:     # builds without the switch keep their default
+        pass
+
 
 def _encoder_layer(layer, x):
     """nn.TransformerEncoderLayer.forward for an unbatched [L, d] input, post-norm, exact GELU, dropout 0
