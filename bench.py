@@ -178,7 +178,14 @@ def parity_vs_reference():
     ref_r, ref_l = torch.from_numpy(g['recon_sub']).double(), torch.from_numpy(g['spatial_sub']).double()
     mse = float(((rec - ref_r) ** 2).mean())
     rng = float(ref_r.max() - ref_r.min())
+    # the train step itself at full size against the reference's forward + backward (fixture full_cfg2_step)
+    from oracle.parity_checks import full_step_errors
+    step = full_step_errors(model)
     return {'workload': 'cfg1: reconstruct(), S2RGB 3x256x256, batch 2, full-size model, deterministic fill',
+            'train_step': {'workload': 'full-size model, B=2 S2RGB 256x256, train-mode forward (injected noise) + '
+                                       'Charbonnier + 1e-6 KL + backward vs the REFERENCE (tests/golden/full_cfg2_step.npz)',
+                           **{k: (round(v, 9) if isinstance(v, float) else v) for k, v in step.items()}},
+            'train_loss_rel_err': step['loss_rel_err'], 'grad_worst_rel_err': step['grad_worst_norm_rel_err'],
             'reference': 'reference CPU fp32 output (tests/golden/full_cfg1.npz, every 8th pixel / 2nd latent)',
             'recon_max_rel_err': float((rec - ref_r).abs().max() / ref_r.abs().max()),
             'latent_max_rel_err': float((lat - ref_l).abs().max() / ref_l.abs().max()),

@@ -346,6 +346,71 @@ def full_size(R):
          keys=np.array(list(ref.state_dict().keys())))
 
 
+def sample_index(numel, k=16):
+    """k deterministic flat indices of a tensor of `numel` elements (both sides regenerate them)."""
+    return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def full_step(R):
+    """The path bench.py times, at FULL size, on the reference itself: new_autoencoder.py:587-690 (train-mode
+    forward with the posterior noise injected, loss, backward) on the configs/eo-vae.yaml model, B=2, S2RGB
+    256x256, Charbonnier reconstruction loss (the reference config's rec_loss_type; the L1 value is stored
+    beside it).  Stored: loss scalars, a reconstruction subsample, the global gradient norm, and for EVERY
+    parameter its gradient's L2 norm + 16 sampled entries (SURVEY 8(c)(2) style)."""
+    print('full-size cfg2 train-step fixture (B=2, S2RGB, 256x256, forward + backward) -- takes ~2 min')
+    from einops import rearrange
+    F = torch.nn.functional
+    cfg = O.model_cfg()
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    O.det_fill(ref, seed=31)
+    ref.train()
+    ns = {'torch': torch, 'nn': torch.nn, 'F': F}
+    Charb = ref_class_from_source(os.path.join(REF, 'eo_vae/models/modules/consistency_loss.py'),
+                                  'CharbonnierLoss', ns)
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    eps = hashed((2, 32, 32, 32), 1600, 1.0)
+    post = ref.encode(x, wvs)
+    z = post.mean + post.std * eps                       # distributions.py:44-46 with the draw injected
+    zs = rearrange(z, '... c (i pi) (j pj) -> ... (c pi pj) i j', pi=2, pj=2)
+    recon = ref.decode(ref._normalize_latent(zs), wvs)   # new_autoencoder.py:466-478
+    char = Charb()(recon, x)                             # consistency_loss.py:12-21 (eps 1e-3)
+    l1 = F.l1_loss(recon, x)
+    kl = post.kl()
+    loss = char + 1e-6 * kl.mean()
+    loss.backward()
+    named = [('encoder.' + k, p) for k, p in ref.encoder.named_parameters()] + \
+            [('decoder.' + k, p) for k, p in ref.decoder.named_parameters()]
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)))
+    names = np.array([k for k, _ in named])
+    norms = np.array([p.grad.double().norm().item() for _, p in named])
+    samples = np.stack([npy(p.grad).reshape(-1)[sample_index(p.numel())] for _, p in named])
+    bn_mean, bn_var = npy(ref.bn.running_mean), npy(ref.bn.running_var)
+
+    # the oracle on the same step (asserted, as for every other fixture)
+    mine = O.build_vae(cfg)
+    O.det_fill(mine, seed=31)
+    mine.train()
+    rec_o, post_o = mine(x, wvs, noise=eps)
+    loss_o = O.charbonnier(rec_o, x) + 1e-6 * post_o.kl().mean()
+    loss_o.backward()
+    close(rec_o, recon, 1e-4, 'full_step.recon')
+    close(loss_o, loss, 2e-5, 'full_step.loss')
+    po = dict(mine.named_parameters())
+    tot = gnorm
+    worst = 0.0
+    for (k, p), n in zip(named, norms):
+        err = (po[k].grad.double() - p.grad.double()).norm().item()
+        worst = max(worst, err / max(n, 1e-3 * tot))
+    assert worst < 2e-4, f'oracle != reference for full_step gradients: {worst}'
+    print(f'  oracle vs reference: worst per-tensor gradient error {worst:.2e}')
+    save('full_cfg2_step', x_checksum=np.float64(x.double().sum().item()), eps=npy(eps),
+         recon_sub=npy(recon[:, :, ::8, ::8]), loss=np.float64(loss.item()), charbonnier=np.float64(char.item()),
+         l1=np.float64(l1.item()), kl=npy(kl), grad_norm=np.float64(gnorm), grad_names=names,
+         grad_norms=norms, grad_samples=samples, bn_running_mean=bn_mean, bn_running_var=bn_var)
+
+
 def extra_losses(R):
     """SAM / gradient-difference / focal-frequency branches of EOConsistencyLoss.
     consistency_loss.py cannot be imported as a whole (top-level torchmetrics import), so its
@@ -568,7 +633,7 @@ if __name__ == '__main__':
               ('extra_losses', lambda: extra_losses(R)), ('eqvae', lambda: eqvae(R)),
               ('distill', lambda: distill(R)),
               ('running_stats', running_stats), ('batch_prep', batch_prep),
-              ('full_size', lambda: full_size(R))]
+              ('full_size', lambda: full_size(R)), ('full_step', lambda: full_step(R))]
     for name, fn in groups:
         if not only or name in only:
             fn()

@@ -190,3 +190,27 @@ def test_full_size_kernel_properties():
             # and the GroupNorm that consumes the tag equals one that measures the tensor itself
             assert rel(ops.group_norm_silu(yb_, gamma, beta), ops.group_norm_silu(yb_.clone(), gamma, beta)) < 2e-6
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16c8'])
+def test_full_size_train_step_against_reference(golden, mode):
+    """The path bench.py times, at FULL size, against the REFERENCE's own forward + backward (fixture
+    `full_cfg2_step`: new_autoencoder.py:587-690 on the configs/eo-vae.yaml model, B=2, S2RGB 256x256, injected
+    posterior noise, Charbonnier + 1e-6 KL; loss scalars, reconstruction, and for each of the 363 - 3 parameter
+    tensors the gradient's norm and 16 sampled entries).  north_star bars: loss 1e-4, reconstruction 1e-3; the
+    gradient bar is this repository's own (grad_bar()) and the measured worst case is printed, not hidden."""
+    from eo_vae_amd import ops
+    from oracle.parity_checks import full_step_errors
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, mode
+    try:
+        _, prod = build_pair({}, 31)
+        e = full_step_errors(prod, golden('full_cfg2_step'))
+        print(mode, e)
+        assert e['loss_rel_err'] <= REL_LOSS and e['charbonnier_rel_err'] <= REL_LOSS and e['l1_rel_err'] <= REL_LOSS, e
+        assert e['recon_max_rel_err'] <= REL_OUT and e['kl_max_rel_err'] <= REL_OUT, e
+        assert e['grad_norm_rel_err'] <= REL_OUT, e
+        bar = grad_bar()
+        assert e['grad_worst_norm_rel_err'] <= bar and e['grad_worst_sample_rel_err'] <= 4 * bar, e
+        assert e['bn_mean_rel_err'] <= stat_bar() and e['bn_var_rel_err'] <= stat_bar(), e
+    finally:
+        ops.CONV_PRECISION = old

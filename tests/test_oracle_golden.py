@@ -170,6 +170,30 @@ def test_full_cfg1_reconstruct(golden):
     assert_close(m.encode_spatial_normalized(x, wvs)[:, :, ::2, ::2], g['spatial_sub'], 1e-4, 'spatial')
 
 
+def test_full_cfg2_step_fixture(golden):
+    """BASELINE config 2's step at full size (B=2): the oracle's forward + backward against the fixture the
+    REFERENCE wrote (loss scalars, reconstruction, every parameter gradient's norm) -- ~45 s on 8 threads."""
+    g = golden('full_cfg2_step')
+    assert abs(float(np.sqrt((g['grad_norms'] ** 2).sum())) - float(g['grad_norm'])) < 1e-9 * float(g['grad_norm'])
+    torch.set_num_threads(8)
+    m = O.build_vae(O.model_cfg()).train()
+    O.det_fill(m, seed=31)
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    rec, post = m(x, wvs, noise=torch.from_numpy(g['eps']))
+    char = O.charbonnier(rec, x)
+    loss = char + 1e-6 * post.kl().mean()
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 2e-5 * abs(float(g['loss']))
+    assert abs(torch.nn.functional.l1_loss(rec, x).item() - float(g['l1'])) <= 2e-5 * float(g['l1'])
+    assert_close(rec[:, :, ::8, ::8], g['recon_sub'], 1e-4, 'recon')
+    po = dict(m.named_parameters())
+    tot = float(g['grad_norm'])
+    for k, n in zip(g['grad_names'], g['grad_norms']):
+        got = po[str(k)].grad.double().norm().item()
+        assert abs(got - n) <= 2e-4 * max(n, 1e-3 * tot), (k, got, n)
+
+
 # ---- MS-SSIM: PARITY UNPINNED (torchmetrics absent) -> known-answer properties (SURVEY 8c) ----
 
 def test_msssim_properties():
