@@ -1,0 +1,55 @@
+// Shared by the f16c8 3x3 convolution kernels (conv_f16c8.hip: 8 waves, 2 x 2 blocks per wave;
+// conv_f16c8_w4.hip: 4 waves, one per SIMD, 4 x 4 blocks per wave): argument block, operand typedefs, scale helpers.
+#pragma once
+#include "eovae_common.h"
+
+struct ConvCArgs {
+  const float* x;
+  const unsigned char* wp;   // f16c8-packed weights, 16 KiB per (tap, 32-ch chunk, 128-co block) + header
+  const float* bias;
+  const float* res;
+  float* y;
+  const unsigned* xamax;     // |x| amax as float bits (device), or null: x is used unscaled
+  int N, Cin, Hin, Win, Cout, Hout, Wout;
+  int nchunk, ncob;
+  int mode;
+  int tiles_x, tiles_y;
+  int subpix, creal, cpb;    // as ConvBArgs (conv_bf16x3.hip)
+  int xcd_remap;
+  int ntiles;                // tiles x co-blocks walked by the persistent grid
+  int packed;                // x = f16c8 operand records (GroupNorm-apply, forward only)
+  double* gn_sums;           // [N][gn_groups][2] += (sum, sum of squares) of the OUTPUT per (image, channel group), or null
+  int gn_groups, gn_shift;   // channel groups of the GroupNorm that reads y; log2(channels per group)
+};
+
+namespace {
+
+enum { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_ZINS = 3 };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+
+// x of the lane whose index within its quad is permuted by CTRL (0xB1: lane ^ 1, 0x4E: lane ^ 2)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// power of two 2^k as a float, k clamped to the normal range
+__device__ __forceinline__ float pow2f(int k) {
+  k = k < -126 ? -126 : (k > 127 ? 127 : k);
+  return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+}
+// binary exponent of a positive float given as bits (0 for zero / subnormal input)
+__device__ __forceinline__ int expo_of_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xff);
+  return e == 0 ? -127 : e - 127;
+}
+
+}  // namespace
+
+// conv_f16c8_w4.hip: launches the one-wave-per-SIMD kernel for an argument block prepared by eovae_conv3x3_f16c8_fwd
+// (plain 3x3 form, full 16 x 32 tiles only); returns false when the layer does not qualify.
+bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu);
+void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st);

@@ -1,0 +1,517 @@
+// 3x3 stride-1 convolution / data gradient with f16c8 operands -- ONE WAVE PER SIMD, 4 x 4 register blocking.
+//
+// Same arithmetic, operand formats, weight packs and C-ABI entry as conv_f16c8.hip (x*w ~= f16(x)*f16(w) on
+// v_mfma_f32_32x32x16_f16 + one K-concatenated block-scaled fp8 correction product on
+// v_mfma_scale_f32_32x32x64_f8f6f4); what changes is the shape of the work on a CU:
+//
+//   conv_f16c8.hip      8 waves (2 per SIMD, <= 256 registers), wave tile 2 co-tiles x 2 pixel rows of 32 x 32,
+//                       block tile 128 co x 8 rows x 32 px: per tap a wave reads 16 KB of fragments for 12 MFMAs
+//   this file           4 waves (1 per SIMD, the whole 512-register file: 256 accumulators + 256 vector registers),
+//                       wave tile 4 co-tiles x 4 pixel rows, block tile 128 co x 16 rows x 32 px: per tap a wave
+//                       reads 32 KB of fragments for 48 MFMAs -- half the LDS bytes, half the weight traffic and a
+//                       1.2 x halo (18 x 34 / 16 x 32) instead of 1.33 x per MFMA.
+//
+// Pipeline of one (tile, 32-channel chunk) = 18 PHASES of 1024 MFMA cycles each:
+//     phases 0..8   the nine taps' f16 products      (32 x v_mfma_f32_32x32x16_f16, reads the f16 halo image)
+//     phases 9..17  the nine taps' fp8 corrections   (16 x v_mfma_scale_f32_32x32x64_f8f6f4, reads the fp8 halo image)
+// so each of the two halo images (39 KB) is idle for half a chunk, and that is when the NEXT chunk's half is written
+// into it (f16 image at phase 8, fp8 image at phase 17): single-buffered images, no barrier pair around a refill, no
+// bubble at chunk or tile boundaries.  The next chunk travels global -> registers (phases 0..4) -> converted in
+// place (phases 3..7, fp32 inputs only) -> LDS.  Weights: 8 KB per phase, global -> registers two phases ahead ->
+// a 3-slot LDS ring (slot = phase % 3: the streamed A fragments of phase p are still being read during phase p); every load is a plain load, so the compiler counts vmcnt exactly and no
+// hand-counted wait is needed.  Within a phase the MFMAs run co-tile by co-tile: the A fragments of co-tile i+1 and
+// one row of the next phase's B fragments are requested in front of co-tile i's MFMAs (A: 2 x 8 registers, streamed;
+// B: 2 x 32 registers, double buffered across phases).
+// One workgroup barrier per phase publishes the weight slot and the halo writes.
+//
+// Restrictions (the host falls back to conv_f16c8.hip otherwise): plain 3x3 form (no sub-pixel / space-to-depth),
+// Cout % 128 == 0, Cin % 32 == 0, Hout % 16 == 0, Wout % 32 == 0, at least two tiles per CU.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_f16c8_common.h"
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+#ifndef EOVAE_W4_SGB
+#define EOVAE_W4_SGB 1   // scheduling-group pattern inside a co-tile group (experiment hook)
+#endif
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
+  constexpr int TH = 16, TW = 32, BM = 128, KC = 32;
+  constexpr int XW = TW + 2, NPX = (TH + 2) * XW;          // 18 x 34 = 612 halo pixels
+  constexpr int IMG = 4 * NPX * 16;                         // one halo image: f16 [4 octets][pixel][8 ch] = 39168 B;
+  constexpr int OFF_X8 = IMG;                               // fp8 [lo' | hi'][2 x 16 ch][pixel][16 B] = the same size
+  constexpr int OFF_W = 2 * IMG, WPART = 8192, NSLOT = 3;   // weight ring: 3 slots of one phase's 8 KB (slot = phase % 3)
+  constexpr int OFF_GN = OFF_W + NSLOT * WPART;
+  constexpr int GNS = 4 * 2 * 16 * 16 * 4;                  // GroupNorm partials [wave][sum | sumsq][batch][lane quad]
+  constexpr int NTASK = 10;                                 // halo tasks per thread: wave w stages channel octet w,
+                                                            // lane l pixels l, l + 64, ... (612 = 9 x 64 + 36)
+  constexpr int OFF_DUMMY = OFF_GN + GNS;                   // 1 KB that swallows the writes of the last task's idle lanes
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_DUMMY + 1024];
+  static_assert(OFF_DUMMY + 1024 <= 160 * 1024, "LDS");
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wrow = wave * 4;
+  const size_t in_plane = (size_t)a.Hin * a.Win;
+  const size_t out_plane = (size_t)a.Hout * a.Wout;
+
+  struct Tile { int cob, n, oy0, ox0; };
+  auto decode = [&](int b) {
+    Tile t;
+    if (a.xcd_remap) {  // the ncob blocks sharing one halo tile take consecutive slots of ONE XCD
+      const int xcd = b & 7, q = b >> 3;
+      t.cob = q % a.ncob;
+      b = (q / a.ncob) * 8 + xcd;
+    } else {
+      t.cob = b % a.ncob;
+      b /= a.ncob;
+    }
+    const int tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    t.n = b / a.tiles_y;
+    t.oy0 = ty * TH;
+    t.ox0 = tx * TW;
+    return t;
+  };
+
+  // operand scales, as conv_f16c8.hip
+  float xs = 1.f, xinv = 1.f;
+  if (a.xamax) {
+    const unsigned bits = *a.xamax;
+    if (bits) {
+      const int e = expo_of_bits(bits);
+      xs = pow2f(13 - e);
+      xinv = pow2f(e - 13);
+    }
+  }
+  const unsigned wbits = *reinterpret_cast<const unsigned*>(a.wp + (size_t)9 * a.nchunk * a.ncob * 16384);
+  const int e1 = wbits ? 7 - expo_of_bits(wbits) : 0;
+  auto e8m0 = [](int k) { k += 127; return k < 0 ? 0 : (k > 254 ? 254 : k); };
+  const int sc_a = e8m0(-e1 - 12);
+  const int sc_b = e8m0(0);
+
+  // ---------------------------------------------------------------- halo staging (wave = channel octet)
+  constexpr unsigned UNIT = PACKED ? 32u : 4u;   // bytes per pixel step of the source (records / fp32 plane)
+  float xr[NTASK][8];
+  unsigned xoff[NTASK];
+  unsigned xokm = 0;
+  auto setup_x = [&](const Tile& t) __attribute__((always_inline)) {
+    xokm = 0;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // keeps the per-task index math out of the registers that live across the chunk loop
+#pragma unroll
+    for (int k = 0; k < NTASK; ++k) {
+      const int pix = ln + 64 * k;
+      const int rr = (pix * 241) >> 13, cc = pix - XW * rr;   // pix / 34, exact for pix < 640
+      const int vy = t.oy0 + rr - 1, vx = t.ox0 + cc - 1;
+      const bool ok = (pix < NPX) & ((unsigned)vy < (unsigned)a.Hin) & ((unsigned)vx < (unsigned)a.Win);
+      xokm |= (ok ? 1u : 0u) << k;
+      // BYTE offset from the halo origin (oy0 - 1, ox0 - 1); an off-image pixel reads the tile's first pixel instead
+      xoff[k] = UNIT * (unsigned)(ok ? rr * a.Win + cc : a.Win + 1);
+    }
+  };
+  // source of a chunk's octet for this wave: (tile, first channel c0) -> pointer at the halo origin (may lie in front of
+  // the plane: it is only dereferenced at offsets of valid pixels)
+  auto xbase = [&](const Tile& t, int c0) __attribute__((always_inline)) {
+    const long origin = (long)(t.oy0 - 1) * a.Win + (t.ox0 - 1);
+    if (PACKED)
+      return reinterpret_cast<const char*>(a.x) +
+             (((long)t.n * (a.Cin / 8) + c0 / 8 + wave) * (long)in_plane + origin) * 32;
+    return reinterpret_cast<const char*>(a.x) + (((long)t.n * a.Cin + c0 + 8 * wave) * (long)in_plane + origin) * 4;
+  };
+  // LDS destinations of task k: compile-time offsets from two lane bases
+  const unsigned st16 = (unsigned)(wave * (NPX * 16) + lane * 16);
+  const unsigned st8 = (unsigned)(OFF_X8 + ((wave >> 1) * NPX + lane) * 16 + (wave & 1) * 8);
+
+  // fp32 path: channels 4 q .. 4 q + 3 of task k converted in place: xr[k][4q .. 4q+3] = {f16 pair, f16 pair, lo' x 4, hi' x 4}
+  auto convert_half = [&](int k, int q) __attribute__((always_inline)) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const float sm = ((xokm >> k) & 1) ? xs : 0.f;   // validity folded into the scale
+    float v[4], lo[4];
+    int pk[2];
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      v[j] = xr[k][4 * q + j] * sm;
+      v[j + 1] = xr[k][4 * q + j + 1] * sm;
+      int hh;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v[j]), "v"(v[j + 1]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hh), "v"(v[j]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hh), "v"(v[j + 1]));
+      pk[j >> 1] = hh;
+    }
+    s16x2 l0 = {0, 0};
+    l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+    l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+    int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+    h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
+    xr[k][4 * q] = __builtin_bit_cast(float, pk[0]);
+    xr[k][4 * q + 1] = __builtin_bit_cast(float, pk[1]);
+    xr[k][4 * q + 2] = __builtin_bit_cast(float, l0);
+    xr[k][4 * q + 3] = __builtin_bit_cast(float, h0);
+  };
+  // LDS writes of task k.  Register layout per task -- fp32 path: see convert_half; records: [0..3] = 8 x f16,
+  // [4..5] = lo' x 8, [6..7] = hi' x 8 (an off-image pixel is an all-zero record).
+  // (no branch anywhere in the phase sequence: with basic-block boundaries inside it the compiler sinks the MFMA chains
+  // of whole phases towards the epilogue and spills their operands; the idle lanes of the last task -- pixels 612..639
+  // -- write into a dummy area instead)
+  const bool idle9 = lane >= NPX - 64 * (NTASK - 1);
+  auto write16 = [&](int k) __attribute__((always_inline)) {
+    i32x4 hv;
+    if (PACKED) {
+      const int keep = ((xokm >> k) & 1) ? -1 : 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hv[c] = __builtin_bit_cast(int, xr[k][c]) & keep;
+    } else {
+      hv[0] = __builtin_bit_cast(int, xr[k][0]); hv[1] = __builtin_bit_cast(int, xr[k][1]);
+      hv[2] = __builtin_bit_cast(int, xr[k][4]); hv[3] = __builtin_bit_cast(int, xr[k][5]);
+    }
+    const unsigned dst = (k == NTASK - 1 && idle9) ? (unsigned)(OFF_DUMMY + lane * 16) : st16 + k * 1024;
+    *reinterpret_cast<i32x4*>(smem + dst) = hv;
+  };
+  auto write8 = [&](int k) __attribute__((always_inline)) {
+    i32x2 lv, uv;
+    if (PACKED) {
+      const int keep = ((xokm >> k) & 1) ? -1 : 0;
+      lv[0] = __builtin_bit_cast(int, xr[k][4]) & keep; lv[1] = __builtin_bit_cast(int, xr[k][5]) & keep;
+      uv[0] = __builtin_bit_cast(int, xr[k][6]) & keep; uv[1] = __builtin_bit_cast(int, xr[k][7]) & keep;
+    } else {
+      lv[0] = __builtin_bit_cast(int, xr[k][2]); lv[1] = __builtin_bit_cast(int, xr[k][6]);
+      uv[0] = __builtin_bit_cast(int, xr[k][3]); uv[1] = __builtin_bit_cast(int, xr[k][7]);
+    }
+    const bool idle = k == NTASK - 1 && idle9;
+    const unsigned d0 = idle ? (unsigned)(OFF_DUMMY + lane * 16) : st8 + k * 1024;
+    const unsigned d1 = idle ? (unsigned)(OFF_DUMMY + lane * 16 + 8) : st8 + k * 1024 + 2 * NPX * 16;
+    *reinterpret_cast<i32x2*>(smem + d0) = lv;       // part 0: lo'
+    *reinterpret_cast<i32x2*>(smem + d1) = uv;       // part 1: hi'
+  };
+
+  // ---------------------------------------------------------------- weights: 8 KB per phase through registers
+  f32x4 wreg[2][2];
+  // phase q (0..17) of chunk `chunk` of co-block `cob`: taps' f16 halves first, then their fp8 halves
+  auto wsrc = [&](int cob, int chunk, int q) __attribute__((always_inline)) {
+    const int tap = q < 9 ? q : q - 9;
+    return a.wp + ((size_t)(tap * a.nchunk + chunk) * a.ncob + cob) * 16384 + (q < 9 ? 0 : 8192) + tid * 16;
+  };
+  auto w_issue = [&](int set, const unsigned char* src) __attribute__((always_inline)) {
+    wreg[set][0] = *reinterpret_cast<const f32x4*>(src);
+    wreg[set][1] = *reinterpret_cast<const f32x4*>(src + 4096);
+  };
+  auto w_commit = [&](int set, int slot) __attribute__((always_inline)) {
+    unsigned char* dst = smem + OFF_W + slot * WPART + tid * 16;
+    *reinterpret_cast<f32x4*>(dst) = wreg[set][0];
+    *reinterpret_cast<f32x4*>(dst + 4096) = wreg[set][1];
+  };
+
+  // ---------------------------------------------------------------- fragments
+  f32x16 acc[4][4];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  };
+  i32x4 Ab[2][2];        // streamed A fragments: [co-tile parity][k-step (f16) | 16-ch half (fp8)]
+  i32x4 Bb[2][4][2];     // B fragments: [phase parity][pixel row][k-step | half]
+  const unsigned xl16 = (unsigned)(h * (NPX * 16) + (wrow * XW + r) * 16);
+  const unsigned xl8 = (unsigned)(OFF_X8 + (h * 2) * (NPX * 16) + (wrow * XW + r) * 16);
+  const unsigned wl16 = (unsigned)(OFF_W + h * (BM * 16) + r * 16);
+  const unsigned wl8 = (unsigned)(OFF_W + (h * 2) * (BM * 16) + r * 16);
+  // A fragments of co-tile i of phase q into Ab[i & 1]
+  auto read_a = [&](auto qc, auto ic) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
+    constexpr unsigned slot = (unsigned)((q % NSLOT) * WPART);
+    if constexpr (q < 9) {
+      Ab[i & 1][0] = *reinterpret_cast<const i32x4*>(smem + wl16 + slot + i * 512);
+      Ab[i & 1][1] = *reinterpret_cast<const i32x4*>(smem + wl16 + slot + 2 * (BM * 16) + i * 512);
+    } else {
+      Ab[i & 1][0] = *reinterpret_cast<const i32x4*>(smem + wl8 + slot + i * 512);
+      Ab[i & 1][1] = *reinterpret_cast<const i32x4*>(smem + wl8 + slot + BM * 16 + i * 512);
+    }
+  };
+  // B fragments of pixel row j of phase q into Bb[q & 1][j]
+  auto read_b = [&](auto qc, auto jc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, j = decltype(jc)::value;
+    constexpr int tap = q < 9 ? q : q - 9, ky = tap / 3, kx = tap - 3 * ky;
+    constexpr unsigned off = (unsigned)(((ky + j) * XW + kx) * 16);
+    if constexpr (q < 9) {
+      Bb[q & 1][j][0] = *reinterpret_cast<const i32x4*>(smem + xl16 + off);
+      Bb[q & 1][j][1] = *reinterpret_cast<const i32x4*>(smem + xl16 + off + 2 * (NPX * 16));
+    } else {
+      Bb[q & 1][j][0] = *reinterpret_cast<const i32x4*>(smem + xl8 + off);
+      Bb[q & 1][j][1] = *reinterpret_cast<const i32x4*>(smem + xl8 + off + NPX * 16);
+    }
+  };
+  auto mma = [&](auto qc, auto ic) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
+    if constexpr (q < 9) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ab[i & 1][s]),
+                                                            __builtin_bit_cast(f16x8, Bb[q & 1][j][s]), acc[i][j], 0, 0, 0);
+    } else {
+      const i32x8 av = __builtin_shufflevector(Ab[i & 1][0], Ab[i & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const i32x8 bv = __builtin_shufflevector(Bb[q & 1][j][0], Bb[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0 /* A: e4m3 */, 1 /* B: e5m2 */, 0,
+                                                                    sc_a, 0, sc_b);
+      }
+    }
+  };
+
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // ---------------------------------------------------------------- GroupNorm partial sums (as conv_f16c8.hip)
+  float* const gslot = reinterpret_cast<float*>(smem + OFF_GN);
+  auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {
+    // 64 outputs (value v, batch b = (co-tile, channel octet), lane half hh) x 4 waves x 8 lane quads
+    const int out = tid >> 2, sub = tid & 3;
+    const int v = out >> 5, b = (out >> 1) & 15, hh = out & 1;
+    const float* cell = gslot + ((sub * 2 + v) * 16 + b) * 16 + hh * 8;
+    const float4 c0 = *reinterpret_cast<const float4*>(cell), c1 = *reinterpret_cast<const float4*>(cell + 4);
+    float t = ((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w));
+    t += dpp_quad<0xB1>(t);
+    t += dpp_quad<0x4E>(t);
+    const int co = tcb + (b >> 2) * 32 + (b & 3) * 8 + 4 * hh;
+    if (sub == 0) atomicAdd(a.gn_sums + ((size_t)tn * a.gn_groups + (co >> a.gn_shift)) * 2 + v, (double)t);
+  };
+
+  // ---------------------------------------------------------------- epilogue (full tiles only)
+  auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
+    const int co_blk = t.cob * BM;
+    float* yn = a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane;
+    const float* rn = a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : nullptr;
+    // lane part of every address: the lane half's 4 channel planes + its pixel; rows / channels are scalar offsets
+    const unsigned lo0 = (unsigned)(((size_t)(4 * h) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + r) * 4);
+    const unsigned rowb = (unsigned)a.Wout * 4u;
+    const float* bw = a.bias ? a.bias + co_blk : nullptr;
+    auto load_res = [&](float (&rv)[4][4], int b) __attribute__((always_inline)) {
+      if (!rn) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rv[k][j] = 0.f;
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const char* rp = reinterpret_cast<const char*>(rn + (size_t)((b >> 2) * 32 + 8 * (b & 3) + k) * out_plane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[k][j] = *reinterpret_cast<const float*>(rp + j * rowb + lo0);
+      }
+    };
+    float rva[4][4], rvb[4][4];
+    load_res(rva, 0);
+    static_for<0, 16>([&](auto bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value, i = b >> 2, qq = b & 3;
+      float (&rv)[4][4] = (b & 1) ? rvb : rva;
+      float (&rnx)[4][4] = (b & 1) ? rva : rvb;
+      if constexpr (b + 1 < 16) load_res(rnx, b + 1);   // the residual of the next batch rides behind this batch's stores
+      float bias4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bias4[k] = bw ? bw[i * 32 + 8 * qq + k + 4 * h] : 0.f;
+      float v[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k] + rv[k][j];
+      if (a.gn_sums) {   // statistics of the following GroupNorm: the 4 channels of a batch lie in one group
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sv += v[k][j];
+            qv = __builtin_fmaf(v[k][j], v[k][j], qv);
+          }
+        sv += dpp_quad<0xB1>(sv); qv += dpp_quad<0xB1>(qv);
+        sv += dpp_quad<0x4E>(sv); qv += dpp_quad<0x4E>(qv);
+        if ((lane & 3) == 0) {
+          float* cell = gslot + (wave * 32 + b) * 16 + (lane >> 2);
+          cell[0] = sv;
+          cell[16 * 16] = qv;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        char* yp = reinterpret_cast<char*>(yn + (size_t)(i * 32 + 8 * qq + k) * out_plane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float*>(yp + j * rowb + lo0) = v[k][j];
+      }
+    });
+  };
+
+  // ---------------------------------------------------------------- prologue
+  int tile = blockIdx.x;
+  if (tile >= a.ntiles) return;
+  Tile cur = decode(tile);
+  setup_x(cur);
+  {
+    w_issue(0, wsrc(cur.cob, 0, 0));
+    w_issue(1, wsrc(cur.cob, 0, 1));
+    const char* xb = xbase(cur, 0);
+#pragma unroll
+    for (int k = 0; k < NTASK; ++k) {
+      if (PACKED) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(xb + xoff[k]);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { xr[k][c] = q0[c]; xr[k][4 + c] = q1[c]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[k][j] = *reinterpret_cast<const float*>(xb + (size_t)j * in_plane * 4 + xoff[k]);
+      }
+    }
+    w_commit(0, 0);
+    w_commit(1, 1);
+    w_issue(0, wsrc(cur.cob, 0, 2));
+    w_issue(1, wsrc(cur.cob, 0, 3));
+#pragma unroll
+    for (int k = 0; k < NTASK; ++k) {
+      if (!PACKED) { convert_half(k, 0); convert_half(k, 1); }
+      write16(k);
+      write8(k);
+    }
+  }
+  zero_acc();
+  barrier();
+  {
+    using Q0 = std::integral_constant<int, 0>;
+    read_a(Q0{}, Q0{});
+    static_for<0, 4>([&](auto jc) __attribute__((always_inline)) { read_b(Q0{}, jc); });
+  }
+
+  // ---------------------------------------------------------------- main loop
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const bool has_next_tile = tile + (int)gridDim.x < a.ntiles;
+    Tile nxt = cur;
+    if (has_next_tile) nxt = decode(tile + gridDim.x);
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      const bool last_chunk = chunk + 1 == a.nchunk;
+      // the chunk staged behind this one: next chunk, the next tile's first, or (end of work) this chunk again --
+      // re-staging the chunk being multiplied writes the bytes that are already there
+      const bool wrap = last_chunk && has_next_tile;
+      const Tile& xt = wrap ? nxt : cur;
+      const int xchunk = last_chunk ? (has_next_tile ? 0 : chunk) : chunk + 1;
+      if (wrap) setup_x(nxt);
+      const char* xb = xbase(xt, xchunk * KC);
+      static_for<0, 18>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int pn = (p + 1) % 18;
+        using PN = std::integral_constant<int, pn>;
+        barrier();   // weights of phase p + 1 and the halo writes of phase p - 1 are visible; frags(p) have landed
+        // weights of phase p + 2 into slot (p + 2) % 3: its previous tenant, phase p - 1, was last read (streamed A
+        // fragments of co-tiles 1..3) during phase p - 1; loads of phase p + 4 into the freed registers
+        w_commit(p & 1, (p + 2) % NSLOT);
+        if constexpr (p + 4 < 18) w_issue(p & 1, wsrc(cur.cob, chunk, p + 4));
+        else w_issue(p & 1, wsrc(xt.cob, xchunk, p + 4 - 18));
+        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          // fragment requests: next co-tile's A, row i of the next phase's B
+          if constexpr (i < 3) read_a(pc, std::integral_constant<int, i + 1>{});
+          else read_a(PN{}, std::integral_constant<int, 0>{});
+          read_b(PN{}, ic);
+          // staging slice of this group
+          if constexpr (PACKED) {
+            // records: f16 halves of tasks 0..9 in phases 0, 1; [lo' | hi'] halves in phases 9, 10
+            if constexpr (p == 0 || p == 1 || p == 9 || p == 10) {
+              constexpr int half = p >= 9 ? 1 : 0, k0 = 5 * (p - 9 * half);
+              constexpr int first = k0 + (i == 0 ? 0 : i + 1), cnt = i == 0 ? 2 : 1;
+#pragma unroll
+              for (int k = first; k < first + cnt; ++k) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16 * half);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xr[k][4 * half + c] = qv[c];
+              }
+            }
+          } else {
+            // fp32: tasks 2p, 2p+1 loaded in phases 0..4 (channels 2i, 2i+1 in group i), converted three phases later
+            if constexpr (p <= 4) {
+#pragma unroll
+              for (int k = 2 * p; k < 2 * p + 2; ++k)
+#pragma unroll
+                for (int j = 2 * i; j < 2 * i + 2; ++j)
+                  xr[k][j] = *reinterpret_cast<const float*>(xb + (size_t)j * in_plane * 4 + xoff[k]);
+            }
+            if constexpr (p >= 3 && p <= 7) convert_half(2 * (p - 3) + (i >> 1), i & 1);
+          }
+          if constexpr (p == 8) {          // the f16 image is idle from here to phase 17's requests
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k)
+              if ((k & 3) == i) write16(k);
+          }
+          if constexpr (p == 17) {         // the fp8 image is idle from here to the next chunk's phase 8
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k)
+              if ((k & 3) == i) write8(k);
+          }
+          mma(pc, ic);
+#if EOVAE_W4_SGB
+          // spread the requests / staging work over the MFMA gaps instead of in front of the first MFMA
+#pragma unroll
+          for (int m = 0; m < (p < 9 ? 8 : 4); ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x020, p < 9 ? 1 : 2, 0);   // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x002, p < 9 ? 2 : 4, 0);   // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+          }
+#endif
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    epilogue_tile(cur);
+    zero_acc();
+    if (a.gn_sums) {   // uniform.  The cells are rewritten by the next epilogue, a whole tile (>= 18 barriers) later.
+      barrier();
+      gn_flush(cur.n, cur.cob * BM);
+    }
+    cur = nxt;
+  }
+}
+
+}  // namespace
+
+bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu) {
+  const char* env = getenv("EOVAE_C8_W4");   // "0": never, "1": whenever the shape allows (default: when it pays)
+  if (env && env[0] == '0') return false;
+  if (subpix != 0 || a.mode != MODE_NORMAL) return false;
+  if (a.Cout % 128 || a.Cin % 32 || a.Hout % 16 || a.Wout % 32 || a.Hin != a.Hout || a.Win != a.Wout) return false;
+  const long long tiles = (long long)a.N * (a.Hout / 16) * (a.Wout / 32) * (a.Cout / 128);
+  if (env && env[0] == '1') return tiles >= 1;
+  return tiles >= 2LL * n_cu;   // fewer 16-row tiles than two per CU leave CUs idle: the 8-row kernel takes those
+}
+
+void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
+  a.tiles_x = a.Wout / 32;
+  a.tiles_y = a.Hout / 16;
+  const long long sp_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
+  a.xcd_remap = (a.ncob > 1 && sp_tiles % 8 == 0) ? 1 : 0;
+  a.ntiles = (int)(sp_tiles * a.ncob);
+  const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(256);
+  if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false>), grid, blk, 0, st, a);
+}

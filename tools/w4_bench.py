@@ -1,0 +1,46 @@
+"""A/B of the two f16c8 forward / data-gradient kernels at the real layer shapes (B=16), interleaved rounds in ONE
+process (rule 24): EOVAE_C8_W4=0 -> conv_f16c8.hip (8 waves, 2x2 blocks), =1 -> conv_f16c8_w4.hip (4 waves, 4x4 blocks).
+    python tools/w4_bench.py            fp32 input and record input, per layer: ms and algorithmic TFLOP/s"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from eo_vae_amd import ops, lib as L
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+shapes = [(128, 128, 256), (256, 256, 128), (512, 512, 64), (256, 128, 256), (512, 256, 128), (512, 512, 32)]
+B = 16
+lib = L.load()
+ops.CONV_PRECISION = 'f16c8'
+for cin, cout, hw in shapes:
+    x = torch.randn(B, cin, hw, hw, device='cuda')
+    w = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
+    y = torch.empty(B, cout, hw, hw, device='cuda')
+    res = torch.randn_like(y)
+    gns = torch.zeros(B, 32, 2, dtype=torch.float64, device='cuda')
+    bias = torch.randn(cout, device='cuda')
+    amax = ops.absmax_bits(x)
+    flops = 2.0 * B * hw * hw * cin * cout * 9
+    wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
+    L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
+    xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True).detach()
+    cases = {
+        'fwd rec+gn+res': lambda: lib.eovae_conv3x3_f16c8_fwd(L.ptr(xrec), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, L.stream()),
+        'fwd rec+gn    ': lambda: lib.eovae_conv3x3_f16c8_fwd(L.ptr(xrec), L.ptr(wp), L.ptr(bias), None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, L.stream()),
+        'dgrad fp32+amax': lambda: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()),
+    }
+    best = {(k, v): 1e9 for k in cases for v in '01'}
+    for rnd in range(3):
+        for k, f in cases.items():
+            for v in '01':
+                os.environ['EOVAE_C8_W4'] = v
+                best[(k, v)] = min(best[(k, v)], timeit(f))
+    for k in cases:
+        t0, t1 = best[(k, '0')], best[(k, '1')]
+        print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 {k}: 8-wave {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | w4 {t1:7.3f} ms {flops/t1/1e9:6.1f} TF | x{t0/t1:.3f}', flush=True)
