@@ -46,6 +46,26 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define EOVAE_W4_SGB 1   // scheduling-group pattern inside a co-tile group (experiment hook)
 #endif
 
+// Diagnostic build only (-DEOVAE_W4_STAMP=1, tools/w4_stamps.py): shader-clock stamps per tile of the first blocks,
+// written to a buffer nothing else reads.  The product build has no stamp code.
+#ifndef EOVAE_W4_STAMP
+#define EOVAE_W4_STAMP 0
+#endif
+#if EOVAE_W4_STAMP
+#define W4_NPT 6
+#define W4_MAXREC 32
+#define W4_NBLK 8
+__device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
+#define W4_STAMP(id)                                                                                          \
+  do {                                                                                                        \
+    if (lane == 0 && blockIdx.x < W4_NBLK && rec < W4_MAXREC)                                                 \
+      w4_stamps[((blockIdx.x * 4 + wave) * W4_MAXREC + rec) * W4_NPT + (id)] =                                \
+          (id) == 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+#else
+#define W4_STAMP(id) do {} while (0)
+#endif
+
 template <bool PACKED>
 __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   constexpr int TH = 16, TW = 32, BM = 128, KC = 32;
@@ -298,66 +318,111 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   };
 
   // ---------------------------------------------------------------- epilogue (full tiles only)
+  // The accumulators hold one PIXEL per lane and 16 channels per block (channel = 8 qq + 4 h + k in register
+  // 4 qq + k), so the natural store is a dword per lane: 256 store and (with a residual) 256 load instructions per
+  // lane and tile, and the CU retires one such instruction per ~20 cycles whatever its width (stamps: 19 k cycles of
+  // epilogue per tile without, 40-45 k with a residual, against 74 k MFMA cycles of a 128-channel tile; a deeper
+  // residual prefetch and a start stagger between CUs changed nothing, tools/w4_stamps.py).  So each batch of
+  // 4 channels x 4 pixels is TRANSPOSED inside its lane quad (DPP, 1 VALU instruction per value): lane 4 pq + m
+  // then owns channel 8 qq + 4 h + m at pixels 4 pq .. 4 pq + 3, and every load / store moves 16 bytes per lane --
+  // eight complete 128-byte lines per instruction, a quarter of the instructions.
+  // (Swapping the MFMA operands gives a lane four consecutive pixels without a transpose, but then its 64 lanes sit in
+  // 32 different channel planes: 32 scattered 32-byte sectors per instruction ran 2.5 x SLOWER than dword stores.)
+  auto quad_transpose = [&](float (&v)[4], bool e0, bool e1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {   // lane bit 0 <-> register bit 0
+      const float send = e0 ? v[c] : v[c + 1];
+      const float rcv = dpp_quad<0xB1>(send);
+      v[c] = e0 ? rcv : v[c];
+      v[c + 1] = e0 ? v[c + 1] : rcv;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {      // lane bit 1 <-> register bit 1
+      const float send = e1 ? v[c] : v[c + 2];
+      const float rcv = dpp_quad<0x4E>(send);
+      v[c] = e1 ? rcv : v[c];
+      v[c + 2] = e1 ? v[c + 2] : rcv;
+    }
+  };
   auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
     const int co_blk = t.cob * BM;
-    float* yn = a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane;
-    const float* rn = a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : nullptr;
-    // lane part of every address: the lane half's 4 channel planes + its pixel; rows / channels are scalar offsets
-    const unsigned lo0 = (unsigned)(((size_t)(4 * h) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + r) * 4);
-    const unsigned rowb = (unsigned)a.Wout * 4u;
-    const float* bw = a.bias ? a.bias + co_blk : nullptr;
-    auto load_res = [&](float (&rv)[4][4], int b) __attribute__((always_inline)) {
-      if (!rn) {
+    const int m = lane & 3, pq = (lane >> 2) & 7;
+    const bool e0 = lane & 1, e1 = lane & 2;
+    // Buffer addressing, and NO branch in the epilogue: descriptors over the block's 128 channel planes of y and of the
+    // residual and over its 128 bias values; an absent residual / bias is a descriptor of ZERO bytes, whose loads
+    // return 0 by the hardware's range check.  (With `if (residual)` branches between the batches the register
+    // allocator copied the accumulators out of the AGPRs early and spilled 140 registers.)
+    // Lane offset after the transpose: channel 4 h + m of the batch's octet, the wave's first row, its pixel
+    // quartet; batch and row are the scalar offset.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned span = (unsigned)(BM * out_plane * 4);
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+        a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane, 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, a.res ? span : 0u,
+        0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias ? a.bias + co_blk : a.y), 0, a.bias ? (unsigned)(BM * 4) : 0u, 0x00020000);
+    const int lot = (int)(((size_t)(4 * h + m) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * pq) * 4);
+    const int lob = (4 * h + m) * 4;
+    const int oct = (int)(8 * out_plane * 4), rowb = a.Wout * 4;
+    // One accumulator block (co-tile i, row j: 16 channels x this lane's pixel) at a time, so that each 16-register
+    // accumulator tuple leaves the AGPRs once and is consumed at once; its residual (4 x 16 bytes) is requested two
+    // blocks ahead (three rotating buffers).
+    auto load_res = [&](f32x4 (&rv)[4], int t) __attribute__((always_inline)) {   // t = 4 i + j
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) rv[k][j] = 0.f;
-        return;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const char* rp = reinterpret_cast<const char*>(rn + (size_t)((b >> 2) * 32 + 8 * (b & 3) + k) * out_plane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rv[k][j] = *reinterpret_cast<const float*>(rp + j * rowb + lo0);
-      }
+      for (int qq = 0; qq < 4; ++qq)
+        rv[qq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrd, lot, ((t >> 2) * 4 + qq) * oct + (t & 3) * rowb, 0));
     };
-    float rva[4][4], rvb[4][4];
-    load_res(rva, 0);
-    static_for<0, 16>([&](auto bc) __attribute__((always_inline)) {
-      constexpr int b = decltype(bc)::value, i = b >> 2, qq = b & 3;
-      float (&rv)[4][4] = (b & 1) ? rvb : rva;
-      float (&rnx)[4][4] = (b & 1) ? rva : rvb;
-      if constexpr (b + 1 < 16) load_res(rnx, b + 1);   // the residual of the next batch rides behind this batch's stores
-      float bias4[4];
+    f32x4 rv0[4], rv1[4], rv2[4];
+    load_res(rv0, 0);
+    load_res(rv1, 1);
+    float sv[4], qv[4], bias1[4];
+    static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t >> 2, j = t & 3;
+      f32x4 (&rv)[4] = (t % 3 == 0) ? rv0 : ((t % 3 == 1) ? rv1 : rv2);
+      f32x4 (&rnx)[4] = ((t + 2) % 3 == 0) ? rv0 : (((t + 2) % 3 == 1) ? rv1 : rv2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (t + 2 < 16) load_res(rnx, t + 2);
+      if constexpr (j == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bias4[k] = bw ? bw[i * 32 + 8 * qq + k + 4 * h] : 0.f;
-      float v[4][4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k] + rv[k][j];
-      if (a.gn_sums) {   // statistics of the following GroupNorm: the 4 channels of a batch lie in one group
-        float sv = 0.f, qv = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            sv += v[k][j];
-            qv = __builtin_fmaf(v[k][j], v[k][j], qv);
-          }
-        sv += dpp_quad<0xB1>(sv); qv += dpp_quad<0xB1>(qv);
-        sv += dpp_quad<0x4E>(sv); qv += dpp_quad<0x4E>(qv);
-        if ((lane & 3) == 0) {
-          float* cell = gslot + (wave * 32 + b) * 16 + (lane >> 2);
-          cell[0] = sv;
-          cell[16 * 16] = qv;
+        for (int qq = 0; qq < 4; ++qq) {
+          bias1[qq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bsrd, lob, (i * 4 + qq) * 32, 0));
+          sv[qq] = 0.f;
+          qv[qq] = 0.f;
         }
       }
+      const f32x16 blk = acc[i][j];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        char* yp = reinterpret_cast<char*>(yn + (size_t)(i * 32 + 8 * qq + k) * out_plane);
+      for (int qq = 0; qq < 4; ++qq) {
+        float w[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float*>(yp + j * rowb + lo0) = v[k][j];
+        for (int k = 0; k < 4; ++k) w[k] = blk[4 * qq + k];
+        quad_transpose(w, e0, e1);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[k] = __builtin_fmaf(w[k], xinv, bias1[qq]) + rv[qq][k];
+          sv[qq] += o[k];
+          qv[qq] = __builtin_fmaf(o[k], o[k], qv[qq]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, (i * 4 + qq) * oct + j * rowb, 0);
+      }
+      if constexpr (j == 3) {
+        // statistics of the following GroupNorm (the quad's 4 channels lie in one group); written unconditionally,
+        // read by gn_flush() only when the caller asked for them
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          float s1 = sv[qq], q1 = qv[qq];
+          s1 += dpp_quad<0xB1>(s1); q1 += dpp_quad<0xB1>(q1);
+          s1 += dpp_quad<0x4E>(s1); q1 += dpp_quad<0x4E>(q1);
+          float* cell = gslot + (wave * 32 + i * 4 + qq) * 16 + (lane >> 2);
+          if ((lane & 3) == 0) {
+            cell[0] = s1;
+            cell[16 * 16] = q1;
+          }
+        }
       }
     });
   };
@@ -365,6 +430,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   // ---------------------------------------------------------------- prologue
   int tile = blockIdx.x;
   if (tile >= a.ntiles) return;
+  // Start stagger (experiment hook EOVAE_C8_W4_STAGGER, default off): eight block groups start
+  // group x stagger x 1024 cycles apart.  Measured: no gain at 3 / 6 / 10.
+  if (a.stagger) {
+    const int g = (blockIdx.x >> 3) & 7;
+    for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   Tile cur = decode(tile);
   setup_x(cur);
   {
@@ -403,7 +474,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   }
 
   // ---------------------------------------------------------------- main loop
+#if EOVAE_W4_STAMP
+  int rec = 0;
+#endif
   for (; tile < a.ntiles; tile += gridDim.x) {
+    W4_STAMP(0);
+    W4_STAMP(5);
     const bool has_next_tile = tile + (int)gridDim.x < a.ntiles;
     Tile nxt = cur;
     if (has_next_tile) nxt = decode(tile + gridDim.x);
@@ -483,17 +559,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       });
     }
+    W4_STAMP(1);
     epilogue_tile(cur);
+    W4_STAMP(2);
     zero_acc();
+    W4_STAMP(3);
     if (a.gn_sums) {   // uniform.  The cells are rewritten by the next epilogue, a whole tile (>= 18 barriers) later.
       barrier();
       gn_flush(cur.n, cur.cob * BM);
     }
+    W4_STAMP(4);
+#if EOVAE_W4_STAMP
+    ++rec;
+#endif
     cur = nxt;
   }
 }
 
 }  // namespace
+
+#if EOVAE_W4_STAMP
+extern "C" int eovae_debug_w4_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(w4_stamps), bytes < sizeof(w4_stamps) ? bytes : sizeof(w4_stamps));
+}
+#endif
 
 bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu) {
   const char* env = getenv("EOVAE_C8_W4");   // "0": never, "1": whenever the shape allows (default: when it pays)
@@ -511,6 +600,8 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   const long long sp_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
   a.xcd_remap = (a.ncob > 1 && sp_tiles % 8 == 0) ? 1 : 0;
   a.ntiles = (int)(sp_tiles * a.ncob);
+  const char* sg = getenv("EOVAE_C8_W4_STAGGER");
+  a.stagger = sg ? atoi(sg) : 0;
   const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(256);
   if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true>), grid, blk, 0, st, a);
   else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false>), grid, blk, 0, st, a);
