@@ -1600,7 +1600,7 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   ConvCArgs a;
   a.x = x; a.wp = (const unsigned char*)wp; a.bias = bias; a.res = residual; a.y = y; a.xamax = xamax;
   a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1; a.packed = xpacked;
-  a.stagger = 0;
+  a.stagger = 0; a.skew = 0;
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && !xamax), "conv3x3_f16c8_fwd: packed input is a forward, plain 3x3 input");
   if (subpix == 0) {
     const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;

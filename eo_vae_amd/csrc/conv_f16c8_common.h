@@ -21,6 +21,7 @@ struct ConvCArgs {
   double* gn_sums;           // [N][gn_groups][2] += (sum, sum of squares) of the OUTPUT per (image, channel group), or null
   int gn_groups, gn_shift;   // channel groups of the GroupNorm that reads y; log2(channels per group)
   int stagger;               // conv_f16c8_w4.hip: start delay per block group, in units of 1024 shader cycles
+  int skew;                  // conv_f16c8_w4.hip, two blocks per CU: start delay of a CU's second block, units of 4096 cycles
 };
 
 namespace {

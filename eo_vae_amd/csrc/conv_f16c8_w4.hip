@@ -52,38 +52,44 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define EOVAE_W4_STAMP 0
 #endif
 #if EOVAE_W4_STAMP
-#define W4_NPT 6
+#define W4_NPT 7
 #define W4_MAXREC 32
 #define W4_NBLK 8
 __device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
 #define W4_STAMP(id)                                                                                          \
-  do {                                                                                                        \
-    if (lane == 0 && blockIdx.x < W4_NBLK && rec < W4_MAXREC)                                                 \
-      w4_stamps[((blockIdx.x * 4 + wave) * W4_MAXREC + rec) * W4_NPT + (id)] =                                \
-          (id) == 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                        \
+  do {   /* blocks 0..3 and 256..259: a CU's first and (two blocks per CU) second block */                    \
+    const int sb_ = (int)((blockIdx.x >> 8) * 4 + (blockIdx.x & 255));                                         \
+    if (lane == 0 && (blockIdx.x & 255) < 4 && blockIdx.x < 512 && rec < W4_MAXREC)                            \
+      w4_stamps[((sb_ * 4 + wave) * W4_MAXREC + rec) * W4_NPT + (id)] =                                        \
+          (id) == 5 ? __builtin_amdgcn_s_memrealtime()                                                        \
+                    : ((id) == 6 ? (unsigned long long)__builtin_amdgcn_s_getreg(63492) /* HW_ID, 32 bits */           \
+                                 : __builtin_amdgcn_s_memtime());                                                     \
   } while (0)
 #else
 #define W4_STAMP(id) do {} while (0)
 #endif
 
-template <bool PACKED>
-__global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
-  constexpr int TH = 16, TW = 32, BM = 128, KC = 32;
-  constexpr int XW = TW + 2, NPX = (TH + 2) * XW;          // 18 x 34 = 612 halo pixels
+// NI = pixel rows per wave: 4 (16-row tiles, one block per CU, 512 registers per wave) or 2 (8-row tiles, TWO blocks
+// per CU with 256 registers per wave, started half a tile apart so that one block's epilogue -- which is bound by the
+// bytes a CU can move, ~13 B/clk, whatever the instruction width -- runs beside the other block's MFMAs).
+template <bool PACKED, int NI>
+__global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
+  constexpr int TH = 4 * NI, TW = 32, BM = 128, KC = 32;
+  constexpr int XW = TW + 2, NPX = (TH + 2) * XW;          // 18 x 34 = 612 (10 x 34 = 340) halo pixels
   constexpr int IMG = 4 * NPX * 16;                         // one halo image: f16 [4 octets][pixel][8 ch] = 39168 B;
   constexpr int OFF_X8 = IMG;                               // fp8 [lo' | hi'][2 x 16 ch][pixel][16 B] = the same size
   constexpr int OFF_W = 2 * IMG, WPART = 8192, NSLOT = 3;   // weight ring: 3 slots of one phase's 8 KB (slot = phase % 3)
   constexpr int OFF_GN = OFF_W + NSLOT * WPART;
   constexpr int GNS = 4 * 2 * 16 * 16 * 4;                  // GroupNorm partials [wave][sum | sumsq][batch][lane quad]
-  constexpr int NTASK = 10;                                 // halo tasks per thread: wave w stages channel octet w,
+  constexpr int NTASK = (NPX + 63) / 64;                    // halo tasks per thread: wave w stages channel octet w,
                                                             // lane l pixels l, l + 64, ... (612 = 9 x 64 + 36)
   constexpr int OFF_DUMMY = OFF_GN + GNS;                   // 1 KB that swallows the writes of the last task's idle lanes
   __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_DUMMY + 1024];
-  static_assert(OFF_DUMMY + 1024 <= 160 * 1024, "LDS");
+  static_assert(OFF_DUMMY + 1024 <= (NI == 2 ? 80 : 160) * 1024, "LDS");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wrow = wave * 4;
+  const int wrow = wave * NI;
   const size_t in_plane = (size_t)a.Hin * a.Win;
   const size_t out_plane = (size_t)a.Hout * a.Wout;
 
@@ -236,17 +242,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   };
 
   // ---------------------------------------------------------------- fragments
-  f32x16 acc[4][4];
+  f32x16 acc[4][NI];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
   };
   i32x4 Ab[2][2];        // streamed A fragments: [co-tile parity][k-step (f16) | 16-ch half (fp8)]
-  i32x4 Bb[2][4][2];     // B fragments: [phase parity][pixel row][k-step | half]
+  i32x4 Bb[2][NI][2];     // B fragments: [phase parity][pixel row][k-step | half]
   const unsigned xl16 = (unsigned)(h * (NPX * 16) + (wrow * XW + r) * 16);
   const unsigned xl8 = (unsigned)(OFF_X8 + (h * 2) * (NPX * 16) + (wrow * XW + r) * 16);
   const unsigned wl16 = (unsigned)(OFF_W + h * (BM * 16) + r * 16);
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
     constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
     if constexpr (q < 9) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ab[i & 1][s]),
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
     } else {
       const i32x8 av = __builtin_shufflevector(Ab[i & 1][0], Ab[i & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NI; ++j) {
         const i32x8 bv = __builtin_shufflevector(Bb[q & 1][j][0], Bb[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0 /* A: e4m3 */, 1 /* B: e5m2 */, 0,
                                                                     sc_a, 0, sc_b);
@@ -369,22 +375,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
     // One accumulator block (co-tile i, row j: 16 channels x this lane's pixel) at a time, so that each 16-register
     // accumulator tuple leaves the AGPRs once and is consumed at once; its residual (4 x 16 bytes) is requested two
     // blocks ahead (three rotating buffers).
-    auto load_res = [&](f32x4 (&rv)[4], int t) __attribute__((always_inline)) {   // t = 4 i + j
+    auto load_res = [&](f32x4 (&rv)[4], int t) __attribute__((always_inline)) {   // t = NI i + j
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
         rv[qq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrd, lot, ((t >> 2) * 4 + qq) * oct + (t & 3) * rowb, 0));
+                                               rsrd, lot, ((t / NI) * 4 + qq) * oct + (t % NI) * rowb, 0));
     };
     f32x4 rv0[4], rv1[4], rv2[4];
     load_res(rv0, 0);
     load_res(rv1, 1);
     float sv[4], qv[4], bias1[4];
-    static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value, i = t >> 2, j = t & 3;
+    static_for<0, 4 * NI>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t / NI, j = t % NI;
       f32x4 (&rv)[4] = (t % 3 == 0) ? rv0 : ((t % 3 == 1) ? rv1 : rv2);
       f32x4 (&rnx)[4] = ((t + 2) % 3 == 0) ? rv0 : (((t + 2) % 3 == 1) ? rv1 : rv2);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (t + 2 < 16) load_res(rnx, t + 2);
+      if constexpr (t + 2 < 4 * NI) load_res(rnx, t + 2);
       if constexpr (j == 0) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, (i * 4 + qq) * oct + j * rowb, 0);
       }
-      if constexpr (j == 3) {
+      if constexpr (j == NI - 1) {
         // statistics of the following GroupNorm (the quad's 4 channels lie in one group); written unconditionally,
         // read by gn_flush() only when the caller asked for them
 #pragma unroll
@@ -435,6 +441,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   if (a.stagger) {
     const int g = (blockIdx.x >> 3) & 7;
     for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  // Two blocks per CU (NI == 2): the CU's second block (odd workgroup slot, HW_ID.TG_ID) starts half a tile late, so
+  // that from then on one block's epilogue falls into the other's phase sequence.  Nothing is lost while it sleeps:
+  // the first block has the matrix pipes to itself.  (Placement is a speed matter only.)
+  if (NI == 2 && a.skew) {
+    const unsigned tg = __builtin_amdgcn_s_getreg(7172);   // hwreg(HW_REG_HW_ID, 16, 4): workgroup slot on the CU
+    if (tg & 1)
+      for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(64);
   }
   Tile cur = decode(tile);
   setup_x(cur);
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   {
     using Q0 = std::integral_constant<int, 0>;
     read_a(Q0{}, Q0{});
-    static_for<0, 4>([&](auto jc) __attribute__((always_inline)) { read_b(Q0{}, jc); });
+    static_for<0, NI>([&](auto jc) __attribute__((always_inline)) { read_b(Q0{}, jc); });
   }
 
   // ---------------------------------------------------------------- main loop
@@ -480,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   for (; tile < a.ntiles; tile += gridDim.x) {
     W4_STAMP(0);
     W4_STAMP(5);
+    W4_STAMP(6);
     const bool has_next_tile = tile + (int)gridDim.x < a.ntiles;
     Tile nxt = cur;
     if (has_next_tile) nxt = decode(tile + gridDim.x);
@@ -508,15 +523,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
           // fragment requests: next co-tile's A, row i of the next phase's B
           if constexpr (i < 3) read_a(pc, std::integral_constant<int, i + 1>{});
           else read_a(PN{}, std::integral_constant<int, 0>{});
-          read_b(PN{}, ic);
+          if constexpr (i < NI) read_b(PN{}, ic);
           // staging slice of this group
           if constexpr (PACKED) {
             // records: f16 halves of tasks 0..9 in phases 0, 1; [lo' | hi'] halves in phases 9, 10
             if constexpr (p == 0 || p == 1 || p == 9 || p == 10) {
-              constexpr int half = p >= 9 ? 1 : 0, k0 = 5 * (p - 9 * half);
-              constexpr int first = k0 + (i == 0 ? 0 : i + 1), cnt = i == 0 ? 2 : 1;
+              constexpr int TPP = (NTASK + 1) / 2;   // tasks per phase
+              constexpr int half = p >= 9 ? 1 : 0, k0 = TPP * (p - 9 * half);
 #pragma unroll
-              for (int k = first; k < first + cnt; ++k) {
+              for (int k = k0; k < k0 + TPP && k < NTASK; ++k) {
+                if (((k - k0) & 3) != i) continue;
                 const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16 * half);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xr[k][4 * half + c] = qv[c];
@@ -524,14 +540,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
             }
           } else {
             // fp32: tasks 2p, 2p+1 loaded in phases 0..4 (channels 2i, 2i+1 in group i), converted three phases later
-            if constexpr (p <= 4) {
+            if constexpr (2 * p < NTASK) {
 #pragma unroll
-              for (int k = 2 * p; k < 2 * p + 2; ++k)
+              for (int k = 2 * p; k < 2 * p + 2 && k < NTASK; ++k)
 #pragma unroll
                 for (int j = 2 * i; j < 2 * i + 2; ++j)
                   xr[k][j] = *reinterpret_cast<const float*>(xb + (size_t)j * in_plane * 4 + xoff[k]);
             }
-            if constexpr (p >= 3 && p <= 7) convert_half(2 * (p - 3) + (i >> 1), i & 1);
+            if constexpr (p >= 3 && 2 * (p - 3) + (i >> 1) < NTASK) convert_half(2 * (p - 3) + (i >> 1), i & 1);
           }
           if constexpr (p == 8) {          // the f16 image is idle from here to phase 17's requests
 #pragma unroll
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
 #if EOVAE_W4_SGB
           // spread the requests / staging work over the MFMA gaps instead of in front of the first MFMA
 #pragma unroll
-          for (int m = 0; m < (p < 9 ? 8 : 4); ++m) {
+          for (int m = 0; m < (p < 9 ? 2 * NI : NI); ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
             __builtin_amdgcn_sched_group_barrier(0x020, p < 9 ? 1 : 2, 0);   // VMEM read
@@ -584,25 +600,48 @@ extern "C" int eovae_debug_w4_stamps(void* dst, size_t bytes) {
 }
 #endif
 
+// rows per wave: 4 = 16-row tiles, one block per CU (default).  2 = 8-row tiles, two skewed blocks per CU: an
+// EXPERIMENT (EOVAE_C8_W4_NI=2, record inputs only) that did not pay -- the CU's older block wins the issue arbitration,
+// finishes its eight tiles in 0.69 M cycles while the younger one needs 0.93 M, and the layer takes as long as with
+// one block per CU (tools/w4_stamps.py).  fp32 inputs always take 4 rows per wave: the 2-row fp32
+// variant spills 50 registers into the phase sequence and is not used.
+static int w4_rows_per_wave(const ConvCArgs& a, int n_cu) {
+  const char* env = getenv("EOVAE_C8_W4_NI");
+  (void)n_cu;
+  if (env && env[0] == '2' && a.packed && a.Hout % 8 == 0) return 2;
+  return a.Hout % 16 == 0 ? 4 : 0;
+}
+
 bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu) {
   const char* env = getenv("EOVAE_C8_W4");   // "0": never, "1": whenever the shape allows (default: when it pays)
   if (env && env[0] == '0') return false;
   if (subpix != 0 || a.mode != MODE_NORMAL) return false;
-  if (a.Cout % 128 || a.Cin % 32 || a.Hout % 16 || a.Wout % 32 || a.Hin != a.Hout || a.Win != a.Wout) return false;
-  const long long tiles = (long long)a.N * (a.Hout / 16) * (a.Wout / 32) * (a.Cout / 128);
+  if (a.Cout % 128 || a.Cin % 32 || a.Wout % 32 || a.Hin != a.Hout || a.Win != a.Wout) return false;
+  const int ni = w4_rows_per_wave(a, n_cu);
+  if (!ni) return false;
+  const long long tiles = (long long)a.N * (a.Hout / (4 * ni)) * (a.Wout / 32) * (a.Cout / 128);
   if (env && env[0] == '1') return tiles >= 1;
-  return tiles >= 2LL * n_cu;   // fewer 16-row tiles than two per CU leave CUs idle: the 8-row kernel takes those
+  return tiles >= (ni == 2 ? 4LL : 2LL) * n_cu;   // fewer tiles than two per block leave CUs idle: the 8-wave kernel takes those
 }
 
 void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
+  const int ni = w4_rows_per_wave(a, n_cu);
   a.tiles_x = a.Wout / 32;
-  a.tiles_y = a.Hout / 16;
+  a.tiles_y = a.Hout / (4 * ni);
   const long long sp_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
   a.xcd_remap = (a.ncob > 1 && sp_tiles % 8 == 0) ? 1 : 0;
   a.ntiles = (int)(sp_tiles * a.ncob);
   const char* sg = getenv("EOVAE_C8_W4_STAGGER");
   a.stagger = sg ? atoi(sg) : 0;
-  const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(256);
-  if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false>), grid, blk, 0, st, a);
+  const char* sk = getenv("EOVAE_C8_W4_SKEW");   // experiment hook: units of 4096 cycles; default = half a tile
+  a.skew = ni == 2 ? (sk ? atoi(sk) : (a.nchunk * 7 + 2) / 5) : 0;
+  const int nblk = ni == 2 ? 2 * n_cu : n_cu;
+  const dim3 grid((unsigned)(a.ntiles < nblk ? a.ntiles : nblk)), blk(256);
+  if (ni == 2) {
+    if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 2>), grid, blk, 0, st, a);
+  } else {
+    if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4>), grid, blk, 0, st, a);
+  }
 }

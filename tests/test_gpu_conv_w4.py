@@ -16,17 +16,21 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-@pytest.fixture(autouse=True)
-def f16c8_mode():
+@pytest.fixture(autouse=True, params=['4', '2'])
+def f16c8_mode(request):
+    """Both tile shapes of the kernel: 4 rows per wave (16-row tiles, one block per CU) and 2 rows per wave (8-row
+    tiles, two skewed blocks per CU)."""
     from eo_vae_amd import ops
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
-    env = os.environ.get('EOVAE_C8_W4')
+    env = {k: os.environ.get(k) for k in ('EOVAE_C8_W4', 'EOVAE_C8_W4_NI')}
+    os.environ['EOVAE_C8_W4_NI'] = request.param
     yield
     ops.CONV_PRECISION = old
-    if env is None:
-        os.environ.pop('EOVAE_C8_W4', None)
-    else:
-        os.environ['EOVAE_C8_W4'] = env
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def run(fn, w4):

@@ -23,7 +23,7 @@ L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.s
 for _ in range(30):   # warm: clocks settle under load
     L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(xrec), L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, L.stream()), 'fwd')
 torch.cuda.synchronize()
-NPT, MAXREC, NBLK = 6, 32, 8
+NPT, MAXREC, NBLK = 7, 32, 8
 buf = np.zeros(NBLK * 4 * MAXREC * NPT, dtype=np.uint64)
 fn = C.CDLL(L.LIB_PATH).eovae_debug_w4_stamps
 fn.argtypes = [C.c_void_p, C.c_size_t]
@@ -31,6 +31,12 @@ assert fn(buf.ctypes.data, buf.nbytes) == 0
 t = buf.reshape(NBLK, 4, MAXREC, NPT).astype(np.int64)
 nchunk = cin // 32
 print(f'{cin}->{cout} @{hw}^2 res={use_res}: {nchunk} chunks x 18 phases = {nchunk * 18 * 1024} MFMA cycles per tile')
+t00 = int(t[0, 0, 0, 0])
+for blk in range(NBLK):
+    hw = int(t[blk, 0, 0, 6])
+    n = sum(1 for rec in range(MAXREC) if t[blk, 0, rec, 0])
+    print(f'slot {blk} (block {(blk >> 2) * 256 + (blk & 3)}): first tile starts at {int(t[blk, 0, 0, 0]) - t00:9d}, last tile ends at {int(t[blk, 0, n - 1, 4]) - t00 if n else -1:9d} cycles after block 0 started; {n} tiles')
+    print(f'block {blk}: HW_ID {hw:#010x}  wave slot {hw & 15} simd {(hw >> 4) & 3} cu {(hw >> 8) & 15} sh {(hw >> 12) & 1} se {(hw >> 13) & 7} tg {(hw >> 16) & 15}')
 for blk in range(0, NBLK, 2):
     for wave in (0, 3):
         rows = []
