@@ -810,18 +810,6 @@ __device__ __forceinline__ int wg_src_index(int mode, int oy0, int ox0, int r, i
 #define EOVAE_WGRAD_BLOCKS 256
 #endif
 
-struct WgCArgs {
-  const float* x;
-  const float* dy;
-  float* db;   // [Cout] bias gradient (sum of dy over n, pixels), pre-zeroed, or null
-  float* dwp;  // [9][Cout][Cin] fp32, pre-zeroed
-  const unsigned* dyamax;   // float bits of max|dy| (device) or null
-  int N, Cin, Hin, Win, Cout, Hout, Wout;
-  int mode;
-  int tiles_x, tiles_y, ntiles, ncib;
-  int subpix, creal, cpb;   // as WgBArgs (conv_bf16x3.hip)
-  int ncob_, split, xcd_remap;
-};
 
 // XPACKED: x is the f16c8 operand-record tensor GroupNorm-apply wrote (32 B per pixel and channel octet): an X task is
 // two 16-byte loads and three LDS stores, no conversion (plain layers only: SUBPIX 0, mode NORMAL, Cin % 64 == 0).
@@ -1725,6 +1713,13 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
   a.xcd_remap = (a.ncib * ncob > 1 && split % 8 == 0) ? 1 : 0;
   dim3 grid(a.ncib * ncob * split);
   hipStream_t st = (hipStream_t)stream;
+  a.xpacked = xpacked;
+  // one-wave-per-SIMD kernel (conv_f16c8_wgrad_w4.hip) for plain layers made of full tiles
+  if (eovae_c8_wgrad_w4_eligible(a)) {
+    eovae_c8_wgrad_w4_launch(a, st);
+    EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad (w4)");
+    return EOVAE_OK;
+  }
   if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1, false>), grid, dim3(512), 0, st, a);
   else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2, false>), grid, dim3(512), 0, st, a);
   else if (xpacked) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, true>), grid, dim3(512), 0, st, a);

@@ -24,6 +24,21 @@ struct ConvCArgs {
   int skew;                  // conv_f16c8_w4.hip, two blocks per CU: start delay of a CU's second block, units of 4096 cycles
 };
 
+// weight-gradient argument block (conv_f16c8.hip wgrad3x3_f16c8_kernel, conv_f16c8_wgrad_w4.hip)
+struct WgCArgs {
+  const float* x;
+  const float* dy;
+  float* db;   // [Cout] bias gradient (sum of dy over n, pixels), pre-zeroed, or null
+  float* dwp;  // [9][Cout][Cin] fp32, pre-zeroed
+  const unsigned* dyamax;   // float bits of max|dy| (device) or null
+  int N, Cin, Hin, Win, Cout, Hout, Wout;
+  int mode;
+  int tiles_x, tiles_y, ntiles, ncib;
+  int subpix, creal, cpb;   // as WgBArgs (conv_bf16x3.hip)
+  int ncob_, split, xcd_remap;
+  int xpacked;              // x = f16c8 operand records (GroupNorm-apply)
+};
+
 namespace {
 
 enum { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_ZINS = 3 };
@@ -55,3 +70,7 @@ __device__ __forceinline__ int expo_of_bits(unsigned bits) {
 // (plain 3x3 form, full 16 x 32 tiles only); returns false when the layer does not qualify.
 bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu);
 void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st);
+
+// conv_f16c8_wgrad_w4.hip: one-wave-per-SIMD weight gradient (plain 3x3 form, full tiles)
+bool eovae_c8_wgrad_w4_eligible(const WgCArgs& a);
+void eovae_c8_wgrad_w4_launch(WgCArgs a, hipStream_t st);
