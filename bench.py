@@ -92,6 +92,28 @@ def wgrad_roofline(wtimer, peak, elapsed, prec):
             'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
 
 
+def traffic_ratios(src, alg_bytes):
+    """PMC traffic of the dominant kernel against its algorithmic bytes, with the raw FETCH_SIZE and with the gfx950
+    x2 correction (calibrated for 16-byte-per-lane streams; dword-per-lane loads lie between the two)."""
+    try:
+        return {'raw': round((src['fetch_bytes_raw'] + src['write_bytes']) / alg_bytes, 3),
+                'corrected': round((2 * src['fetch_bytes_raw'] + src['write_bytes']) / alg_bytes, 3)}
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
+
+
+def conv8_roofline(timer, peak, elapsed):
+    """The 3x3 forward / data-gradient launches that stay on the 8-wave kernel (sub-pixel and space-to-depth forms, grids
+    below two 16-row tiles per CU), measured like `roofline`."""
+    ms, flops, n = timer.totals(0)
+    if n == 0 or ms <= 0:
+        return None
+    ach = flops / (ms * 1e-3)
+    return {'bound': 'mfma', 'kernel': 'conv3x3_f16c8_kernel (8 waves: sub-pixel / space-to-depth forms and small grids)',
+            'achieved': round(ach / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'launches': n, 'achieved_per_launch_ms': round(ms / n, 4), 'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
+
+
 def build_model(channels, kl_weight=1e-6, msssim=False):
     from eo_vae_amd.autoencoder import EOFluxVAE
     from eo_vae_amd.losses import EOConsistencyLoss
@@ -137,11 +159,36 @@ class StepDriver:
         return loss
 
 
+def host_cpu():
+    """(model name, physical cores, logical CPUs this process may use) of the box's host."""
+    model, phys = 'unknown', set()
+    try:
+        pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                pid = v
+            elif k == 'core id':
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return model, (len(phys) or logical), logical
+
+
 def cpu_baseline(channels, wvs_list, micro_batch=2, threads=None):
-    """Oracle (CPU restatement, kind 'port') timed on this box's host cores: one full train step
-    at a bounded micro-batch (B=16 needs ~56 GB of saved activations on the host)."""
+    """Oracle (CPU restatement, kind 'port') timed on this box's host cores: full train steps at a
+    bounded micro-batch (B=16 needs ~56 GB of saved activations on the host), 1 warm-up + 3 timed, threads = the
+    physical cores this process may use (capped at 32: the oracle's conv kernels stop scaling there)."""
     from oracle import eo_vae_cpu as O
-    threads = threads or min(os.cpu_count() or 8, 16)
+    model_name, phys, logical = host_cpu()
+    threads = threads or max(1, min(phys, logical, 32))
     torch.set_num_threads(threads)
     m = O.build_vae(O.model_cfg(channels=channels))
     O.det_fill(m, seed=31)
@@ -150,12 +197,55 @@ def cpu_baseline(channels, wvs_list, micro_batch=2, threads=None):
     loss_fn = O.EOConsistencyLoss(pixel_weight=1.0, rec_loss_type='l1', kl_weight=1e-6)
     wvs = torch.tensor(wvs_list)
     x = O.synthetic_batch(micro_batch, channels, 256, seed=99)
-    t0 = time.time()
-    st.step(loss_fn, x, wvs)
-    dt = time.time() - t0
+    st.step(loss_fn, x, wvs)            # warm-up (allocator, thread pool, oneDNN primitive caches)
+    times = []
+    for _ in range(3):
+        t0 = time.time()
+        st.step(loss_fn, x, wvs)
+        times.append(time.time() - t0)
+    dt = sum(times) / len(times)
     return {'value': micro_batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'1 full train step (fwd+L1+KL+bwd+clip+Adam) at micro-batch {micro_batch}, '
-                      f'{channels}x256x256, fp32, torch CPU {threads} threads, {dt:.1f} s'}
+            'cpu_model': model_name, 'physical_cores': phys, 'logical_cpus': logical,
+            'sample': f'1 warm-up + 3 timed full train steps (fwd+L1+KL+bwd+clip+Adam) at micro-batch {micro_batch}, '
+                      f'{channels}x256x256, fp32, torch CPU {threads} threads, mean {dt:.1f} s/step '
+                      f'(min {min(times):.1f}, max {max(times):.1f})'}
+
+
+# Shader clock the chip holds under the dominant kernel (in-kernel s_memtime / s_memrealtime of the diagnostic build,
+# tools/w4_stamps.py; profiles/r03c_w4_stamps_*.log: 1.66 - 1.77 GHz): what `ceiling` prices the matrix cores at.
+CLOCK_UNDER_LOAD_GHZ = 1.77
+MAX_CLOCK_GHZ = 2.4
+# GroupNorm moves 1.405 GB/img forward, x3 for the step; optimiser + clip + weights 4.8 GB/step
+Q_GN_STEP_PER_IMG = 3 * 1.405e9
+
+
+def ceiling(conv_flops_step, wgrad_flops_step, batch, ips, units=2.0):
+    """How far the north_star's 40 % of the HBM-roofline rate is, from this line alone.
+    matrix-core floor = algorithmic 3x3 flops of the step (forward + data gradient + weight gradient, as timed above)
+    x MFMA units per product (f16c8: 2) / dense peak at the clock the chip HOLDS under this load;
+    HBM floor = the passes no matrix kernel can hide at the HBM peak: GroupNorm (forward apply, backward reduce +
+    apply: SURVEY's 3 x 1.405 GB/img) and optimiser / clip / weight traffic (4.8 GB/step);
+    1x1 / attention GEMMs, losses, the hyper-network and launch gaps are NOT in the floor (they are ~10 ms today)."""
+    flops = conv_flops_step + wgrad_flops_step
+    peak_hold = PEAK_BF16_MFMA * CLOCK_UNDER_LOAD_GHZ / MAX_CLOCK_GHZ
+    t_mfma_hold = flops * units / peak_hold
+    t_mfma_max = flops * units / PEAK_BF16_MFMA
+    t_hbm = (Q_GN_STEP_PER_IMG * batch + Q_STEP_FIXED) / PEAK_HBM
+    r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / batch)
+    out = {
+        'mfma_units_per_product': units, 'clock_under_load_ghz': CLOCK_UNDER_LOAD_GHZ,
+        'matrix_floor_ms_at_held_clock': round(t_mfma_hold * 1e3, 2), 'matrix_floor_ms_at_2.4ghz': round(t_mfma_max * 1e3, 2),
+        'hbm_floor_ms_unfused_passes': round(t_hbm * 1e3, 2),
+        'ceiling_ms_per_step': round((t_mfma_hold + t_hbm) * 1e3, 2),
+        'ceiling_images_per_sec': round(batch / (t_mfma_hold + t_hbm), 1),
+        'ceiling_hbm_roofline_frac': round(batch / (t_mfma_hold + t_hbm) / r_hbm, 4),
+        'target_hbm_roofline_frac': 0.40, 'target_images_per_sec': round(0.40 * r_hbm, 1),
+        'achieved_frac_of_ceiling': round(ips / (batch / (t_mfma_hold + t_hbm)), 4),
+        'note': 'at 100 % MFMA-busy and the clock the chip holds, plus the GroupNorm / optimiser passes at the HBM peak; the '
+                'target needs ~51 ms/step, i.e. this arithmetic (2 units per product) leaves it out of reach unless the '
+                'held clock rises or GroupNorm traffic is fused away',
+    }
+    return out
 
 
 def parity_vs_reference():
@@ -297,9 +387,13 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         ips = args.batch * world * args.steps / elapsed
-        k_ms, k_flops, k_n = timer.totals()
         prec = ops.CONV_PRECISION
-        traffic, traffic_source = pmc_traffic('conv3x3_f16c8_kernel' if prec == 'f16c8' else 'conv3x3_bf16_kernel')
+        # f16c8: the dominant kernel is the one-wave-per-SIMD kernel (kind 1); the launches the 8-wave kernel takes
+        # (sub-pixel / space-to-depth forms, small grids) are reported beside it as `roofline_conv8`
+        dom = 1 if prec == 'f16c8' and timer.totals(1)[2] > 0 else None
+        k_ms, k_flops, k_n = timer.totals(dom)
+        traffic, traffic_source = pmc_traffic(('conv3x3_f16c8_w4_kernel' if dom else 'conv3x3_f16c8_kernel')
+                                              if prec == 'f16c8' else 'conv3x3_bf16_kernel')
         achieved = k_flops / (k_ms * 1e-3) if k_ms > 0 else 0.0
         r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / args.batch)  # img/s per GPU at the HBM roof
         f_img = F_STEP_PER_IMG.get(C, 2.69e12)
@@ -308,7 +402,9 @@ def main():
             path = 'fp32-input MFMA implicit GEMM (exact fp32)'
         elif prec == 'f16c8':
             peak, dtype = PEAK_BF16_MFMA, 'f16c8'
-            kname = 'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)'
+            kname = ('conv3x3_f16c8_w4_kernel (plain 3x3 conv fwd + data-grad: one wave per SIMD, 4x4 register blocking, '
+                     'f16 product + one fp8 correction product)' if dom else
+                     'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)')
             path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) on v_mfma_f32_32x32x16_f16 + ONE K-concatenated '
                     'block-scaled fp8 product [x_lo|x_hi].[w_hi|w_lo] on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 '
                     'accumulate (~1e-5 per product; 2 MFMA units per algorithmic product => frac <= 1/2), forward, data '
@@ -342,10 +438,15 @@ def main():
                          'achieved': round(achieved / 1e12, 2), 'peak': peak / 1e12,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': traffic if prec != 'f32' else None, 'traffic_source': traffic_source,
-                         'algorithmic_bytes_per_launch': round(timer.bytes_total() / max(k_n, 1)),
+                         'traffic_ratio_vs_algorithmic': traffic_ratios(traffic_source, timer.bytes_total(dom) / max(k_n, 1)),
+                         'algorithmic_bytes_per_launch': round(timer.bytes_total(dom) / max(k_n, 1)),
                          'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
+            'roofline_conv8': conv8_roofline(timer, peak, elapsed) if dom else None,
             'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),
+            'ceiling': ceiling(timer.totals()[1] / args.steps, wtimer.totals()[1] / args.steps, args.batch, ips / world,
+                               2.0 if prec == 'f16c8' else (3.0 if prec == 'bf16x3' else (16.0 if prec == 'f32' else 1.0)))
+            if args.workload != 'cfg5' else None,
             'step_ms_events': {'median': round(pick(0.5), 3), 'p10': round(pick(0.1), 3), 'p90': round(pick(0.9), 3)},
             'step_flops_tflops': round(f_img * ips / world / 1e12, 2),
             'hbm_roofline_frac': round(ips / world / r_hbm, 4),

@@ -1573,6 +1573,32 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
   return EOVAE_OK;
 }
 
+static int c8_n_cu() {
+  static int n_cu = 0;   // one persistent block per CU
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    n_cu -= n_cu % 8;   // keeps  tile = blockIdx.x + k * gridDim.x  on one XCD (dealt round-robin)
+    if (n_cu < 8) n_cu = 8;
+  }
+  return n_cu;
+}
+
+// Which kernel eovae_conv3x3_f16c8_fwd launches for these arguments: 1 = conv3x3_f16c8_w4_kernel (one wave per SIMD, 16-row
+// tiles; plain layers that give every CU two tiles), 0 = conv3x3_f16c8_kernel (8 waves, 8-row tiles; every other form).
+// For callers that attribute measured time to a kernel (bench.py); no launch, no device work beyond the first
+// property query.
+int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
+                              int xpacked) {
+  ConvCArgs a;
+  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout; a.mode = mode;
+  a.packed = xpacked;
+  const int n_cu = c8_n_cu();
+  return (n_cu > 0 && subpix == 0 && eovae_c8_w4_eligible(a, subpix, n_cu)) ? 1 : 0;
+}
+
 // 3x3 stride-1 conv / data gradient with f16c8 operands.  Arguments as eovae_conv3x3_bf16_fwd; the GEMM K
 // channel count must be a multiple of 32.  xamax: device pointer to the float bits of max |x|
 // (eovae_absmax_bits) when x may sit outside f16's range (gradients), else NULL.
@@ -1628,17 +1654,10 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   a.tiles_x = cdiv(Wout, 32);
   hipStream_t st = (hipStream_t)stream;
   auto xcd_ok = [&](long long tiles) { return (a.ncob > 1 && tiles % 8 == 0) ? 1 : 0; };
-  static int n_cu = 0;   // one persistent block per CU (142 KiB of LDS each)
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      eovae_set_error("conv3x3_f16c8_fwd: cannot query the device");
-      return EOVAE_ERR_LAUNCH;
-    }
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    n_cu -= n_cu % 8;   // keeps  tile = blockIdx.x + k * gridDim.x  on one XCD (dealt round-robin)
-    if (n_cu < 8) n_cu = 8;
+  const int n_cu = c8_n_cu();
+  if (n_cu < 0) {
+    eovae_set_error("conv3x3_f16c8_fwd: cannot query the device");
+    return EOVAE_ERR_LAUNCH;
   }
   // one-wave-per-SIMD kernel (conv_f16c8_w4.hip: 4 x 4 register blocking, 16-row tiles) for plain layers that give
   // every CU at least two of its tiles

@@ -512,14 +512,18 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
         constexpr int pn = (p + 1) % 18;
         using PN = std::integral_constant<int, pn>;
         barrier();   // weights of phase p + 1 and the halo writes of phase p - 1 are visible; frags(p) have landed
-        // weights of phase p + 2 into slot (p + 2) % 3: its previous tenant, phase p - 1, was last read (streamed A
-        // fragments of co-tiles 1..3) during phase p - 1; loads of phase p + 4 into the freed registers
-        w_commit(p & 1, (p + 2) % NSLOT);
-        if constexpr (p + 4 < 18) w_issue(p & 1, wsrc(cur.cob, chunk, p + 4));
-        else w_issue(p & 1, wsrc(xt.cob, xchunk, p + 4 - 18));
         static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = decltype(ic)::value;
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (i == 1) {
+            // weights of phase p + 2 into slot (p + 2) % 3: its previous tenant, phase p - 1, was last read (streamed
+            // A fragments of co-tiles 1..3) during phase p - 1; loads of phase p + 4 into the freed registers.  Behind
+            // the first co-tile's MFMAs: in front of them (right behind the barrier) the wait for the loads, the two LDS
+            // writes and the address arithmetic sat between the barrier and the phase's first MFMA.
+            w_commit(p & 1, (p + 2) % NSLOT);
+            if constexpr (p + 4 < 18) w_issue(p & 1, wsrc(cur.cob, chunk, p + 4));
+            else w_issue(p & 1, wsrc(xt.cob, xchunk, p + 4 - 18));
+          }
           // fragment requests: next co-tile's A, row i of the next phase's B
           if constexpr (i < 3) read_a(pc, std::integral_constant<int, i + 1>{});
           else read_a(PN{}, std::integral_constant<int, 0>{});

@@ -67,19 +67,20 @@ class KernelTimer:
     def __init__(self):
         self.records = []  # (start_event, end_event, algorithmic_flops)
 
-    def bracket(self, flops, nbytes=0.0):
+    def bracket(self, flops, nbytes=0.0, kind=0):
+        """kind: which kernel of the family takes the launch (3x3 f16c8: 1 = conv3x3_f16c8_w4_kernel, 0 = the rest)."""
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((a, b, flops))
-        self.nbytes = getattr(self, 'nbytes', 0.0) + nbytes
+        self.records.append((a, b, flops, nbytes, kind))
         return a, b
 
-    def bytes_total(self):
-        return getattr(self, 'nbytes', 0.0)
+    def bytes_total(self, kind=None):
+        return sum(r[3] for r in self.records if kind is None or r[4] == kind)
 
-    def totals(self):
+    def totals(self, kind=None):
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        return ms, sum(f for _, _, f in self.records), len(self.records)
+        recs = [r for r in self.records if kind is None or r[4] == kind]
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        return ms, sum(r[2] for r in recs), len(recs)
 
 
 CONV3X3_TIMER: KernelTimer | None = None  # set by bench.py during the timed region
@@ -302,8 +303,9 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
     timed = CONV3X3_TIMER is not None
     if timed:
         pix = (ho * wo) // 4 if mode == MODE_ZINS else ho * wo
+        kind = L.load().eovae_conv3x3_f16c8_which(n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, int(packed)) if f8 else 0
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * pix * cout_gemm * cin_g * 9,
-                                         4.0 * (x.numel() + y.numel() + weight.numel()))
+                                         4.0 * (x.numel() + y.numel() + weight.numel()), kind)
         ev0.record()
     if packed and not f8:
         raise L.EovaeError('conv2d: operand-record input needs the f16c8 kernel (K % 32 == 0, mode normal)')

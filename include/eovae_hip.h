@@ -87,6 +87,11 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                             void* stream);
+/* which kernel the call above launches for these arguments: 1 = conv3x3_f16c8_w4_kernel (csrc/conv_f16c8_w4.hip: one wave
+ * per SIMD, 4 x 4 register blocking, 16-row tiles -- plain layers that give every CU two tiles), 0 =
+ * conv3x3_f16c8_kernel (8 waves, 8-row tiles: sub-pixel / space-to-depth forms, small grids).  No launch. */
+int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
+                              int xpacked);
 /* gn_sums (nullable; meant for the forward calls, any subpix form): [N][gn_groups][2] doubles, zero-filled by the caller; the
  * epilogue adds (sum, sum of squares) of the values it stores (bias and residual included) per image and channel
  * group, i.e. the statistics pass of the GroupNorm(gn_groups) that reads y next (layers.py:91-92, 106-108 follow
