@@ -889,6 +889,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
     }
   }
   const int sc_a = 127 - 12, sc_b = 127;   // E8M0: both K blocks carry one operand scaled by 2^12
+  // x pre-scale (fp32 x only: un-normalised activations -- the residual stream in front of a Downsample / Upsample
+  // layer -- are not bounded like GroupNorm outputs): the power of two that puts max|x| at 2^13..2^14, undone with dy's
+  float xs = 1.f;
+  if (!XPACKED && a.xamax) {
+    const unsigned bits = *a.xamax;
+    if (bits) {
+      const int e = expo_of_bits(bits);
+      xs = pow2f(13 - e);
+      dyinv *= pow2f(e - 13);
+    }
+  }
 
   constexpr int NTA = (NT + 1) / 2;   // taps of group 0 (5 of 9, 2 of 4); group 1 has NT - NTA
   f32x16 acc[NTA][2];                // [tap of the wave's group][co-tile]
@@ -1129,6 +1140,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
           h1 = __builtin_bit_cast(int, xr[i][7]);
         } else {
           float lo[8];
+          if (xs != 1.f) {   // uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[i][j] *= xs;
+          }
 #pragma unroll
           for (int j = 0; j < 8; j += 2) {
             int hp;
@@ -1697,17 +1712,19 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
 }
 
 // dwp[9][Cout][Cin] += dY (x) Xv with f16c8 operands; arguments as eovae_conv3x3_bf16_wgrad plus dyamax
-// (device pointer to the float bits of max|dy|, eovae_absmax_bits / eovae_gn_silu_bwd; NULL = unscaled dy)
-int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db, const unsigned* dyamax, int N,
-                              int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
-                              int xpacked, void* stream) {
+// (device pointer to the float bits of max|dy|, eovae_absmax_bits / eovae_gn_silu_bwd; NULL = unscaled dy) and xamax
+// (the same for an fp32 x that is not a GroupNorm output; NULL = x used unscaled, i.e. assumed inside f16's range)
+int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db, const unsigned* dyamax,
+                              const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                              int mode, int subpix, int xpacked, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_f16c8_wgrad: null pointer");
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_f16c8_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_f16c8_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && mode == MODE_NORMAL && Cin % 64 == 0),
                   "conv3x3_f16c8_wgrad: packed x needs a plain layer with Cin %% 64 == 0");
   WgCArgs a;
-  a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax;
+  EOVAE_CHECK_ARG(!(xpacked && xamax), "conv3x3_f16c8_wgrad: operand records carry no scale (xamax must be NULL)");
+  a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax; a.xamax = xamax;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
   a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
   if (subpix == 1) {

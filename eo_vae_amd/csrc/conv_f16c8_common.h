@@ -31,6 +31,7 @@ struct WgCArgs {
   float* db;   // [Cout] bias gradient (sum of dy over n, pixels), pre-zeroed, or null
   float* dwp;  // [9][Cout][Cin] fp32, pre-zeroed
   const unsigned* dyamax;   // float bits of max|dy| (device) or null
+  const unsigned* xamax;    // float bits of max|x| (device) for an fp32 x that may sit outside f16's range, or null
   int N, Cin, Hin, Win, Cout, Hout, Wout;
   int mode;
   int tiles_x, tiles_y, ntiles, ncib;

@@ -167,15 +167,38 @@ def _tag_amax(t, amax):
 
 # GroupNorm + SiLU can hand its result to the next 3x3 convolution as f16c8 OPERAND RECORDS instead of fp32
 # (csrc/groupnorm.hip gn_apply_packed_kernel): a float32 tensor of the usual [N, C, H, W] shape whose BYTES are the
-# records (N*C*H*W dwords either way).  It is only meaningful to Conv2dFn (plain 3x3, f16c8), which recognises it by
-# this tag; any other consumer raises.
+# records (N*C*H*W dwords either way).  It is only meaningful to Conv2dFn (plain 3x3, f16c8).  The hand-over is a
+# tensor SUBCLASS, so the marking survives detach() / clone() / views / checkpoint recompute (a Python attribute did
+# not, and the bytes were then read as fp32 without any error), and every torch operation that would compute on the
+# bytes raises instead of returning garbage.
+class PackedRecords(torch.Tensor):
+    """f16c8 operand records in a float32 shell: consumable by ops.conv2d (plain 3x3, f16c8 mode) only."""
+
+    _PASS = frozenset({'detach', 'clone', 'contiguous', 'is_contiguous', 'data_ptr', 'size', 'stride', 'dim', 'numel',
+                       'element_size', 'storage_offset', 'untyped_storage', 'requires_grad_', 'retain_grad', 'register_hook',
+                       'view_as', 'is_pinned', 'get_device', 'record_stream', '__get__', '__repr__', '__str__', '__format__',
+                       '__hash__', '__len__', '__reduce_ex__', '__deepcopy__', '__dir__', 'is_floating_point', '_backward_hooks',
+                       'backward', 'grad_fn'})
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        name = getattr(func, '__name__', str(func))
+        if name in ('__repr__', '__str__', '__format__'):
+            t = args[0]
+            return f'PackedRecords(shape={tuple(t.shape)}, device={t.device}: f16c8 operand records, not fp32 values)'
+        if name not in cls._PASS:
+            raise L.EovaeError(f'{name}() on f16c8 operand records (GroupNorm packed output): the bytes are not fp32 values; '
+                               'only the plain 3x3 f16c8 convolution (ops.conv2d) consumes them -- call '
+                               'group_norm_silu(..., packed=False) for an fp32 result')
+        return super().__torch_function__(func, types, args, kwargs or {})
+
+
 def mark_packed(t):
-    t._eovae_packed = t._version
-    return t
+    return t if isinstance(t, PackedRecords) else t.as_subclass(PackedRecords)
 
 
 def is_packed(t):
-    return getattr(t, '_eovae_packed', None) == t._version
+    return isinstance(t, PackedRecords)
 
 
 def packed_ok(channels):
@@ -209,6 +232,18 @@ def gn_sums_of(x, groups):
             and tag[0].device == x.device:
         return tag[0]
     return None
+
+
+# f16c8 operands are f16 / e5m2 values: GroupNorm + SiLU outputs (operand records) are bounded by construction,
+# gradients are pre-scaled from their amax, and -- RANGE_GUARD, on by default -- so is every OTHER fp32 input of a 3x3
+# layer (the residual stream in front of a Downsample / Upsample layer, the latent in front of the decoder's conv_in):
+# one absmax pass per such tensor (7 per step, ~0.3 ms) buys the removal of the |x| < 65 504 assumption.
+RANGE_GUARD = os.environ.get('EOVAE_F16C8_RANGE_GUARD', '1') != '0'
+
+
+def range_amax(x):
+    """absmax bits for the pre-scale of an fp32, not GroupNorm-normalised 3x3-layer input (None: guard off)."""
+    return amax_of(x) if (RANGE_GUARD and CONV_PRECISION == 'f16c8') else None
 
 
 def amax_of(t):
@@ -253,10 +288,13 @@ def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode
                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
 
 
-def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False):
-    """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16."""
+def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False, xamax=None):
+    """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16.
+    xamax: absmax bits of an fp32 x that is not a GroupNorm output (range_amax), or None."""
     lib = L.load()
     amax = amax_of(dy) if CONV_PRECISION == 'f16c8' else None
+    if CONV_PRECISION == 'f16c8' and not packed and xamax is None:
+        xamax = range_amax(x)
     timed = WGRAD3X3_TIMER is not None
     if timed:
         # algorithmic flops of the layer as the reference executes it: 9 taps on the layer's output grid
@@ -264,7 +302,7 @@ def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, p
         ev0, ev1 = WGRAD3X3_TIMER.bracket(2.0 * n * ho * wo * cout * cin * 9, 4.0 * (x.numel() + dy.numel()))
         ev0.record()
     if CONV_PRECISION == 'f16c8':
-        L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), n,
+        L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), L.ptr(xamax), n,
                                               cin, h, w, cout, ho, wo, mode, subpix, int(packed), L.stream()),
                 'eovae_conv3x3_f16c8_wgrad')
     elif packed:
@@ -296,6 +334,8 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
     f8 = _use_f16c8(cin_g) and mode == MODE_NORMAL
     if f8 and flip and amax is None:
         amax = amax_of(x)
+    if f8 and not flip and not packed and amax is None:
+        amax = range_amax(x)
     if wp is None:
         wp = _pack3x3(weight, cout, cin, flip, f8)
     ho, wo = _out_hw(h, w, mode)
@@ -311,7 +351,7 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
         raise L.EovaeError('conv2d: operand-record input needs the f16c8 kernel (K % 32 == 0, mode normal)')
     global _LAST_GN_SUMS
     sums = _gn_sums_buffer(n, cout_gemm, x.device) if f8 and not flip else None
-    _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, amax if flip else None,
+    _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, None if packed else amax,
                packed, sums)
     _LAST_GN_SUMS = sums
     if timed:
@@ -361,7 +401,8 @@ def down_conv_s2d(x, weight, bias):
     y = torch.empty(n, cout, h // 2, w // 2, dtype=torch.float32, device=x.device)
     global _LAST_GN_SUMS
     sums = _gn_sums_buffer(n, cout, x.device) if f8 else None
-    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 3, f8, gn_sums=sums)
+    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 3, f8,
+               range_amax(x) if f8 else None, gn_sums=sums)
     _LAST_GN_SUMS = sums
     return y
 
@@ -377,12 +418,12 @@ def down_conv_s2d_dgrad(dy, weight, h, w):
     return dx
 
 
-def down_conv_s2d_wgrad(x, dy, weight, db=None):
+def down_conv_s2d_wgrad(x, dy, weight, db=None, xamax=None):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * cout * 4 * cin, dtype=torch.float32, device=x.device)
-    _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 2)
+    _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 2, xamax=xamax)
     dw = torch.empty_like(weight)
     L.check(lib.eovae_down_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_down_fold')
     return dw
@@ -401,7 +442,8 @@ def up_conv_subpix(x, weight, bias):
         ev0.record()
     global _LAST_GN_SUMS
     sums = _gn_sums_buffer(n, cout, x.device) if f8 else None
-    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8, gn_sums=sums)
+    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8,
+               range_amax(x) if f8 else None, gn_sums=sums)
     _LAST_GN_SUMS = sums
     if timed:
         ev1.record()
@@ -426,13 +468,13 @@ def up_conv_subpix_dgrad(dy, weight, h, w):
     return dx
 
 
-def up_conv_subpix_wgrad(x, dy, weight, db=None):
+def up_conv_subpix_wgrad(x, dy, weight, db=None, xamax=None):
     """db (f16c8 mode only, pre-zeroed [Cout]): the bias gradient rides on the dy tiles the kernel stages."""
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     lib = L.load()
     dwp = torch.zeros(9 * 4 * cout * cin, dtype=torch.float32, device=x.device)
-    _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1)
+    _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, xamax=xamax)
     dw = torch.empty_like(weight)
     L.check(lib.eovae_subpix_fold(L.ptr(dwp), L.ptr(dw), cout, cin, L.stream()), 'eovae_subpix_fold')
     return dw
@@ -513,6 +555,10 @@ class Conv2dFn(torch.autograd.Function):
             wp, kp, mp = pack_weights(weight, m, False)
             y = conv_raw(x, wp, kp, mp, bias_c, res, cout, ks, m)
         ctx.save_for_backward(x, weight)
+        # the forward's absmax of an un-normalised input serves the weight gradient too (the tag lives on the Python
+        # object, which saved_tensors does not keep)
+        tag = getattr(x, '_eovae_amax', None)
+        ctx.x_amax = tag[0] if (tag is not None and tag[1] == x._version and not packed) else None
         ctx.mode, ctx.has_bias, ctx.has_res = m, bias is not None, residual is not None
         ctx.prec = CONV_PRECISION
         return y
@@ -568,11 +614,11 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and subpix:
             if want_db and CONV_PRECISION == 'f16c8':
                 db = torch.zeros(cout, dtype=torch.float32, device=x.device)
-            dw = up_conv_subpix_wgrad(x, dy, weight, db)
+            dw = up_conv_subpix_wgrad(x, dy, weight, db, getattr(ctx, 'x_amax', None))
         elif ctx.needs_input_grad[1] and s2d:
             if want_db:
                 db = torch.zeros(cout, dtype=torch.float32, device=x.device)
-            dw = down_conv_s2d_wgrad(x, dy, weight, db)
+            dw = down_conv_s2d_wgrad(x, dy, weight, db, getattr(ctx, 'x_amax', None))
         elif ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
             dw = conv1x1_lowp_wgrad(x, dy)
         elif ctx.needs_input_grad[1]:
@@ -581,7 +627,7 @@ class Conv2dFn(torch.autograd.Function):
                 if want_db:  # bias gradient rides on the dy tiles the wgrad kernel stages anyway
                     db = torch.zeros(cout, dtype=torch.float32, device=x.device)
                 _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, dy.shape[2], dy.shape[3], m, 0,
-                                 packed=ctx.packed)
+                                 packed=ctx.packed, xamax=getattr(ctx, 'x_amax', None))
             else:
                 L.check(lib.eovae_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), n, cin, h, w, cout,
                                                dy.shape[2], dy.shape[3], ks, m, L.stream()),
@@ -634,7 +680,7 @@ class GroupNormSiluFn(torch.autograd.Function):
         y, stats = _gn_forward(x, gamma, beta, groups, eps, silu, packed)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
-        return y
+        return mark_packed(y) if packed else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -674,7 +720,7 @@ class GroupNormSiluForkFn(torch.autograd.Function):
         y, stats = _gn_forward(x, gamma, beta, groups, eps, silu, packed)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
-        return y, x.view_as(x)
+        return (mark_packed(y) if packed else y), x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dskip):

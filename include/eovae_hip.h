@@ -102,8 +102,12 @@ int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Ho
  * fp8 MFMA [dy_lo|dy_hi].[x_hi|x_lo].  dyamax as for the data gradient (NULL = dy used unscaled).  db (nullable,
  * pre-zeroed [Cout]) receives sum(dy) in every form, the sub-pixel one included. */
 int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db,
-                              const unsigned* dyamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
-                              int Wout, int mode, int subpix, int xpacked, void* stream);
+                              const unsigned* dyamax, const unsigned* xamax, int N, int Cin, int Hin, int Win,
+                              int Cout, int Hout, int Wout, int mode, int subpix, int xpacked, void* stream);
+/* xamax (nullable, fp32 x only): float bits of max|x| for activations that are not GroupNorm outputs (the residual
+ * stream in front of Downsample / Upsample layers, layers.py:33-37, 47-50): x is pre-scaled by an exact power of two
+ * like dy, so the f16c8 operands make no assumption about its range.  The forward entry takes the same pointer as
+ * its `xamax` argument. */
 /* xpacked = 1 (both entries above): x is not fp32 NCHW but the f16c8 OPERAND-RECORD tensor written by
  * eovae_gn_silu_fwd_packed: [N][C/8][H][W] records of 32 bytes = { 8 x f16 y | 8 x e5m2 (y - f16(y)) * 2^12 |
  * 8 x e5m2 y } for channels 8g..8g+7 -- N*C*H*W dwords, the size of the fp32 activation it replaces.  The

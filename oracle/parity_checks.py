@@ -46,7 +46,7 @@ def full_step_errors(prod, g=None):
     out = {
         'loss_rel_err': rel(loss, g['loss']), 'charbonnier_rel_err': rel(char, g['charbonnier']),
         'l1_rel_err': rel(l1, g['l1']),
-        'kl_max_rel_err': float((kl.double().cpu() - torch.from_numpy(g['kl']).double()).abs().max()
+        'kl_max_rel_err': float((kl.detach().double().cpu() - torch.from_numpy(g['kl']).double()).abs().max()
                                 / torch.from_numpy(g['kl']).double().abs().max()),
         'recon_max_rel_err': float((rec[:, :, ::8, ::8].double().cpu() - ref_r).abs().max() / ref_r.abs().max()),
     }

@@ -53,7 +53,8 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert conv(128, 1, 1, None, None, 0) != 0 and b'packed input' in lib.eovae_last_error()      # records in a sub-pixel form
     assert lib.eovae_conv3x3_f16c8_fwd(fp, fp, None, None, fp, None, 1, 48, 8, 8, 128, 8, 8, 0, 0, 0, None, 0,
                                        None) != 0 and b'multiple of 32' in lib.eovae_last_error()
-    assert lib.eovae_conv3x3_f16c8_wgrad(fp, fp, fp, None, None, 1, 96, 8, 8, 128, 8, 8, 0, 0, 1, None) != 0   # records need Cin % 64
+    assert lib.eovae_conv3x3_f16c8_wgrad(fp, fp, fp, None, None, None, 1, 96, 8, 8, 128, 8, 8, 0, 0, 1, None) != 0   # records need Cin % 64
+    assert lib.eovae_conv3x3_f16c8_wgrad(fp, fp, fp, None, None, fp, 1, 128, 8, 8, 128, 8, 8, 0, 0, 1, None) != 0   # records carry no x scale
     assert lib.eovae_gn_silu_fwd_packed(fp, fp, fp, fp, fp, None, 1, 100, 64, 25, 1e-6, 1, fp, None) != 0 \
         and b'gn_silu_fwd_packed' in lib.eovae_last_error()                                          # C % 8
 
@@ -267,3 +268,21 @@ def test_bench_quotes_hbm_traffic_only_for_the_measured_build_and_mode(monkeypat
     monkeypatch.setattr(ops, 'CONV_PRECISION', ops.DEFAULT_PRECISION)
     val3, src3 = bench.pmc_traffic('conv3x3_f16c8_kernel')
     assert val3 is None and 'kernel sources changed' in src3['stale']
+
+
+def test_packed_records_fail_loudly_outside_the_convolution():
+    """GroupNorm's f16c8 operand records ride in a float32 shell (ops.PackedRecords).  The marking is the tensor's
+    TYPE, so it survives detach() / clone() / contiguous() (a Python attribute did not, and the bytes were
+    then computed on as fp32), and any torch operation on the bytes raises instead of returning garbage."""
+    from eo_vae_amd import ops
+    from eo_vae_amd.lib import EovaeError
+    p = ops.mark_packed(torch.randn(2, 64, 4, 4))
+    assert ops.is_packed(p) and not ops.is_packed(torch.zeros(1))
+    for q in (p.detach(), p.clone(), p.contiguous(), p.detach().requires_grad_(True)):
+        assert ops.is_packed(q) and q.shape == p.shape
+    assert 'operand records' in repr(p)
+    for op in (lambda a: a + 1, lambda a: a * 2.0, lambda a: torch.nn.functional.silu(a), lambda a: a.float(),
+               lambda a: a.sum(), lambda a: a.cpu(), lambda a: a.view(2, -1), lambda a: a[0], lambda a: a.mul_(2),
+               lambda a: torch.cat([a, a]), lambda a: a.numpy()):
+        with pytest.raises(EovaeError, match='operand records'):
+            op(p)

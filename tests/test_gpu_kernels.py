@@ -137,11 +137,42 @@ def test_conv1x1_split_bf16(n, cin, cout, h, w, precision, tol):
     _lowp_case(n, cin, cout, h, w, 1, 'normal', precision, tol)
 
 
-def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol, gscale=1.0):
+@pytest.mark.parametrize('xscale', [1e4, 3e5, 1e-6, 2.0 ** -30])
+@pytest.mark.parametrize('n,cin,cout,h,w,mode', [(2, 32, 128, 32, 32, 'normal'), (2, 128, 128, 32, 32, 'down'),
+                                                 (1, 128, 128, 16, 32, 'up'), (1, 64, 128, 32, 64, 'normal')])
+def test_conv3x3_f16c8_input_range(n, cin, cout, h, w, mode, xscale):
+    """Un-normalised inputs of 3x3 layers (the residual stream in front of Downsample / Upsample, the latent in front
+    of the decoder's conv_in) far outside f16's range -- beyond 65 504 they would become inf, below 6e-5 subnormal:
+    forward, data gradient and weight gradient pre-scale x by the power of two derived from its amax (ops.range_amax),
+    so the result is as accurate as at unit scale.  """
+    _lowp_case(n, cin, cout, h, w, 3, mode, 'f16c8', 1e-4, xscale=xscale)
+
+
+def test_f16c8_range_guard_can_be_switched_off():
+    """EOVAE_F16C8_RANGE_GUARD=0 (ops.RANGE_GUARD) restores the round-2 behaviour: no absmax pass, |x| < 65 504 assumed
+    -- and an input beyond it overflows, which is what the guard is for."""
+    from eo_vae_amd import ops
+    old, oldg = ops.CONV_PRECISION, ops.RANGE_GUARD
+    ops.CONV_PRECISION, ops.RANGE_GUARD = 'f16c8', False
+    try:
+        x = torch.full((1, 32, 16, 32), 1e5, device='cuda')
+        w = torch.ones(128, 32, 3, 3, device='cuda') / 288
+        with torch.no_grad():
+            y = ops.conv2d(x, w, None, None, 'normal')
+        assert not torch.isfinite(y).all()
+        ops.RANGE_GUARD = True
+        with torch.no_grad():
+            y = ops.conv2d(x, w, None, None, 'normal')
+        assert torch.isfinite(y).all() and abs(float(y[0, 0, 8, 16]) / 1e5 - 1.0) < 1e-4
+    finally:
+        ops.CONV_PRECISION, ops.RANGE_GUARD = old, oldg
+
+
+def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol, gscale=1.0, xscale=1.0):
     """bf16x3 (hi*hi + hi*lo + lo*hi on the bf16 MFMA) must be fp32-grade: ~2^-17 per product;
     plain bf16 is the flagged fast mode (2^-9) and only has to be sane."""
     from eo_vae_amd import ops
-    x = hashed((n, cin, h, w), 1, 1.0)
+    x = hashed((n, cin, h, w), 1, 1.0) * xscale
     wt = hashed((cout, cin, ks, ks), 2, 1.0 / (cin * ks * ks) ** 0.5)
     b = hashed((cout,), 3, 0.1)
     xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
@@ -234,5 +265,32 @@ def test_conv_epilogue_groupnorm_sums(n, cin, cout, h, w, res, mode):
         assert rel_err(a_tag.cpu(), a_own.cpu()) < 2e-6
         y.add_(1.0)                                                             # edited in place: tag is void
         assert ops.gn_sums_of(y, 32) is None
+    finally:
+        ops.CONV_PRECISION = old
+
+
+def test_packed_records_survive_detach_and_clone():
+    """detach() / clone() of GroupNorm's operand-record output must not silently turn the bytes into fp32
+    values.  The record tensor is a Tensor subclass: both copies are still records and convolve to the same result."""
+    from eo_vae_amd import ops
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    try:
+        torch.manual_seed(5)
+        x = torch.randn(2, 64, 16, 32, device='cuda')
+        g, b = torch.randn(64, device='cuda'), torch.randn(64, device='cuda')
+        w = torch.randn(128, 64, 3, 3, device='cuda') / 24
+        with torch.no_grad():
+            a = ops.group_norm_silu(x, g, b, packed=True)
+            assert ops.is_packed(a) and ops.is_packed(a.detach()) and ops.is_packed(a.clone())
+            y = ops.conv2d(a, w, None, None, 'normal')
+            assert torch.equal(ops.conv2d(a.detach(), w, None, None, 'normal'), y)
+            assert torch.equal(ops.conv2d(a.clone(), w, None, None, 'normal'), y)
+            ref = ops.conv2d(ops.group_norm_silu(x, g, b, packed=False), w, None, None, 'normal')
+            assert rel_err(y, ref) < 2e-5
+            with pytest.raises(ops.L.EovaeError, match='operand records'):
+                a + 1.0
+            with pytest.raises(ops.L.EovaeError):
+                ops.conv2d(a, torch.randn(128, 64, 1, 1, device='cuda'), None, None, 'normal')   # not a 3x3 consumer
+        torch.cuda.synchronize()
     finally:
         ops.CONV_PRECISION = old

@@ -37,7 +37,7 @@ for cin, cout, hw in shapes:
             if os.environ.get('LB_XPACK') == '1':   # the layer's input as GroupNorm+SiLU operand records (the model's hand-over)
                 xin, xp = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True).detach(), 1
             fns[prec] = (lambda wp=wp, xin=xin, xp=xp: lib.eovae_conv3x3_f16c8_fwd(L.ptr(xin), L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, xp, L.ptr(gns), 32 if gns is not None else 0, L.stream()),
-                         lambda dwp8=dwp8, amax=amax, xin=xin, xp=xp: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(xin), L.ptr(dy), L.ptr(dwp8), None, L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, xp, L.stream()))
+                         lambda dwp8=dwp8, amax=amax, xin=xin, xp=xp: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(xin), L.ptr(dy), L.ptr(dwp8), None, L.ptr(amax), None, B, cin, hw, hw, cout, hw, hw, 0, 0, xp, L.stream()))
         else:
             p = ops._PREC[prec]
             wp = torch.empty(lib.eovae_conv3x3_bf16_packed_elems(cout, cin, 0), dtype=torch.bfloat16, device='cuda')

@@ -26,8 +26,8 @@ for cin, cout, hw in shapes:
     flops = 2.0 * B * hw * hw * cin * cout * 9
     xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True).detach()
     cases = {
-        'x records': lambda: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(xrec), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.stream()),
-        'x fp32   ': lambda: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.stream()),
+        'x records': lambda: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(xrec), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.stream()),
+        'x fp32   ': lambda: lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 0, L.stream()),
     }
     best = {(k, v): 1e9 for k in cases for v in '01'}
     for rnd in range(3):
