@@ -300,7 +300,9 @@ def main():
 
     from eo_vae_amd import ops
     from eo_vae_amd.data import WAVELENGTHS, synthetic_images
+    from eo_vae_amd.dynamic_conv import prefer_rocblas_for_generator
     from eo_vae_amd.parallel import init_distributed
+    blas_backend = prefer_rocblas_for_generator()   # this process is the benchmark's own
 
     rank, world, local = init_distributed()
     if world != args.gpus and not (world == 1 and args.gpus == 1):
@@ -433,7 +435,7 @@ def main():
                                     'cfg5': f'cfg5: {args.modality} {C}-ch 256x256, batch {args.batch}/GPU, encode-only '
                                             '(encode_spatial_normalized + running latent statistics)'}[args.workload],
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'conv_path': path},
+                       'conv_path': path, 'generator_blas': blas_backend},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': round(achieved / 1e12, 2), 'peak': peak / 1e12,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),

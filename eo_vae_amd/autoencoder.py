@@ -287,12 +287,21 @@ class EOFluxVAE(LightningModule):
                 noise: torch.Tensor | None = None):
         """encode -> sample/mode -> (EQ-VAE transform) -> shuffle+BN -> inverse BN+unshuffle -> decode.
         `noise` (optional, beyond the reference signature) injects the posterior noise."""
+        prefetched = False
         if sample_posterior and noise is None:
             noise = self._prefetch_noise(x)
+            prefetched = noise is not None
         posterior = self.encode(x, wvs)
         if sample_posterior and self._lat_geom is None:
             m = posterior.parameters
             self._lat_geom = (m.shape[1] // 2, x.shape[2] // m.shape[2], x.shape[3] // m.shape[3])
+        if prefetched and tuple(noise.shape) != tuple(posterior.mean.shape):
+            # the latent geometry is cached from the first sampled forward as floor ratios; an input whose size is not
+            # a multiple of the down-sampling factor would get noise of another shape.  Never re-drawn silently: the
+            # draw has already advanced the CPU generator the reference's stream depends on.
+            raise ops.L.EovaeError(f'posterior noise was prefetched as {tuple(noise.shape)} but the latent is '
+                                   f'{tuple(posterior.mean.shape)}: input {tuple(x.shape)} does not fit the cached latent '
+                                   'geometry; pass noise= explicitly or set model._lat_geom = None')
         z = posterior.sample(noise) if sample_posterior else posterior.mode()
         if scale is not None or angle is not None:  # EQ-VAE: bilinear scale + rot90 in ONE gather kernel
             size = self._scaled_size(z, scale) if scale is not None else z.shape[-2:]

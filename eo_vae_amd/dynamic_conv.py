@@ -47,17 +47,36 @@ FAST_GENERATOR = os.environ.get('EOVAE_FAST_GENERATOR', '1') != '0'
 
 # The hyper-network's GEMMs are 132-row problems ([132, 256] x [256, 256 .. 2048]).  PyTorch-ROCm's default BLAS
 # (hipBLASLt) picks 256-row macro tiles for them: 19-40 us per call where rocBLAS needs 7-10 (tools/gen_kernels.py).
-# The process-wide preference is switched to rocBLAS here -- every other GEMM of the product runs on its own HIP
-# kernels, so nothing else is affected; EOVAE_GENERATOR_BLAS=keep leaves PyTorch's choice alone.
-if os.environ.get('EOVAE_GENERATOR_BLAS', 'rocblas') == 'rocblas':
-    os.environ.setdefault('DISABLE_ADDMM_CUDA_LT', '1')       # addmm + bias would still go to hipBLASLt
-    try:
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            torch.backends.cuda.preferred_blas_library('cublas')   # = rocBLAS on ROCm
-    except Exception:     # builds without the switch keep their default
-        pass
+# The BLAS preference is PROCESS-WIDE state, so importing this module does not touch it: the entry points
+# that own the process -- trainer.Trainer, train.py, bench.py -- call prefer_rocblas_for_generator(); a host
+# application that embeds the model decides for itself.  EOVAE_GENERATOR_BLAS=keep makes the call a no-op.
+_BLAS_STATE = {'backend': None}
+
+
+def prefer_rocblas_for_generator():
+    """Switch PyTorch's GEMM backend to rocBLAS (process-wide; every other GEMM of this product is its own HIP kernel).
+    Returns the name of the backend in force afterwards; logs it once."""
+    if _BLAS_STATE['backend'] is not None:
+        return _BLAS_STATE['backend']
+    backend = 'default'
+    if os.environ.get('EOVAE_GENERATOR_BLAS', 'rocblas') == 'rocblas':
+        os.environ.setdefault('DISABLE_ADDMM_CUDA_LT', '1')       # addmm + bias would still go to hipBLASLt (read once by
+        try:                                                      # PyTorch: effective when set before the first addmm)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                torch.backends.cuda.preferred_blas_library('cublas')   # = rocBLAS on ROCm
+            backend = str(torch.backends.cuda.preferred_blas_library()).rsplit('.', 1)[-1]
+        except Exception as e:     # builds without the switch keep their default -- said out loud, not swallowed
+            backend = f'default (switch unavailable: {type(e).__name__})'
+    _BLAS_STATE['backend'] = backend
+    print(f'[eo_vae_amd] hyper-network GEMM backend: {backend}', flush=True)
+    return backend
+
+
+def generator_blas_backend():
+    """The backend prefer_rocblas_for_generator() left in force (None: never called in this process)."""
+    return _BLAS_STATE['backend']
 
 
 def _encoder_layer(layer, x):

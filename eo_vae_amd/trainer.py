@@ -36,7 +36,9 @@ class Trainer:
         self.bucket_mb = bucket_mb
         self.val_check_interval = val_check_interval  # validate every N training steps (None: per epoch)
         # The reference's Lightning precision flag (configs/eo-vae.yaml `trainer.precision`):
-        # '32-true' (default) = the parity path (split-bf16, fp32-grade); '16-mixed' / 'bf16-mixed' = the
+        # '32-true' (default) = the parity path (ops.DEFAULT_PRECISION: f16c8 -- f16 product + one fp8 correction
+        # product, 2 MFMA units per product, every north_star tolerance checked at full size against the reference,
+        # DESIGN.md s2 / s4; EOVAE_CONV_PRECISION=bf16x3 selects split-bf16); '16-mixed' / 'bf16-mixed' = the
         # matrix cores on plain bf16 operands with fp32 storage and accumulation -- this build's mixed
         # precision: ~1e-2 relative error, i.e. OUTSIDE the 1e-3 parity bar, opt-in only.
         # The mode is a property of THIS trainer's fit() (ops.precision_scope around the loop), not a
@@ -45,6 +47,8 @@ class Trainer:
         # gfx950 runs f16 and bf16 MFMAs at the same rate and bf16 needs no loss scaling.
         self.precision = str(precision)
         from . import ops
+        from .dynamic_conv import prefer_rocblas_for_generator
+        prefer_rocblas_for_generator()     # process-wide BLAS preference: set by the entry point, not by an import
         self.conv_precision = ops.DEFAULT_PRECISION
         if self.precision in ('16-mixed', 'bf16-mixed', '16', 'bf16'):
             self.conv_precision = 'bf16'

@@ -486,3 +486,27 @@ def test_trainer_mixed_precision_flag(tmp_path):
     assert abs(a[0] - b[0]) < 5e-2 * abs(a[0]) and abs(a[-1] - b[-1]) < 1e-1 * abs(a[-1])
     with pytest.raises(ValueError):
         Trainer(precision='64-true')
+
+
+@pytest.mark.parametrize('ratio,bar', [(0.0, 2e-6), (30.0, 5e-5), (100.0, 5e-4)])
+def test_fused_groupnorm_sums_with_offset_activations(ratio, bar, prec):
+    """the GroupNorm statistics that ride on the conv epilogue are fp32 tile sums of (y, y^2) (double across
+    tiles), and var = E[y^2] - mean^2 cancels when |mean| >> std.  Measured (tools/gn_offset_probe.py): the error of the
+    normalised output grows with (|mean| / std)^2 -- 1e-5 at 30, 1.4e-4 at 100, 1.5e-3 at 300 -- so the fused path
+    holds the 1e-3 bar up to |mean| / std ~ 250 per (image, group); EOVAE_GN_FUSED=0 restores the statistics pass."""
+    from eo_vae_amd import ops
+    if ops.CONV_PRECISION != 'f16c8':
+        pytest.skip('the epilogue sums exist in f16c8 mode only')
+    torch.manual_seed(11)
+    n, c, h, w = 2, 128, 32, 64
+    x = torch.randn(n, c, h, w, device='cuda')
+    wt = torch.randn(c, c, 3, 3, device='cuda') / (c * 9) ** 0.5
+    res = ratio + torch.randn(n, c, h, w, device='cuda')
+    gam, bet = torch.randn(c, device='cuda'), torch.randn(c, device='cuda')
+    with torch.no_grad():
+        a = ops.group_norm_silu(x, torch.ones(c, device='cuda'), torch.zeros(c, device='cuda'), packed=True)
+        y = ops.conv2d(a, wt, None, res, 'normal')
+        assert ops.gn_sums_of(y, 32) is not None
+        fused = ops.group_norm_silu(y, gam, bet)
+        ref = F.silu(F.group_norm(y.double().cpu(), 32, gam.double().cpu(), bet.double().cpu(), eps=1e-6))
+    assert rel(fused, ref) < bar

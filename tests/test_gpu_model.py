@@ -214,3 +214,39 @@ def test_full_size_train_step_against_reference(golden, mode):
         assert e['bn_mean_rel_err'] <= stat_bar() and e['bn_var_rel_err'] <= stat_bar(), e
     finally:
         ops.CONV_PRECISION = old
+
+
+def test_noise_prefetch_reproduces_the_in_sample_draw():
+    """the posterior noise is drawn on the CPU generator BEFORE the encoder is enqueued (pinned double buffer,
+    non-blocking copy).  Seeded, it must be bit-identical to the reference-style draw inside sample() -- first call
+    (geometry unknown: in-sample draw), later calls (prefetched), and across a batch-size change (buffers re-made)."""
+    from oracle import eo_vae_cpu as O
+    _, prod = build_pair(O.TINY, 21)
+    prod.train()
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB']).cuda()
+    xs = [O.synthetic_batch(b, 3, 64, seed=70 + i).cuda() for i, b in enumerate([2, 2, 2, 3, 3])]
+
+    state = {k: v.clone() for k, v in prod.state_dict().items()}
+
+    def run(prefetch):
+        prod.load_state_dict(state)            # the latent BatchNorm's running statistics move with every train-mode forward
+        prod._lat_geom, prod._noise_slots = None, None
+        torch.manual_seed(1234)
+        outs = []
+        for x in xs:
+            if not prefetch:
+                prod._lat_geom = None          # geometry unknown -> every draw happens inside sample()
+            with torch.no_grad():
+                rec, post = prod(x, wvs)
+            outs.append(rec.clone())
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # a geometry the cache does not fit is an error, never a silent re-draw
+    prod._lat_geom = (32, 4, 4)                # wrong on purpose: the tiny model's latent is 8x down
+    with pytest.raises(Exception, match='prefetched'):
+        with torch.no_grad():
+            prod(xs[0], wvs)
+    prod._lat_geom = None
