@@ -27,6 +27,9 @@
 
 namespace {
 
+#ifndef EOVAE_WG4_ABL
+#define EOVAE_WG4_ABL 0   // timing-only experiments (wrong results): 1 no staging, 2 no fragment requests in the loop, 4 no barrier
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -44,12 +47,13 @@ __device__ __forceinline__ f16x8 tr16(const unsigned char* p0, const unsigned ch
   const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(p1));
   return __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+template <int STEP = 256>   // bytes between 8-pixel groups: 8 x the image's pixel pitch
 __device__ __forceinline__ i32x8 tr8(const unsigned char* p) {
   using lds2 = __attribute__((address_space(3))) i32x2;
   const i32x2 v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p));
-  const i32x2 v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 256));
-  const i32x2 v2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 512));
-  const i32x2 v3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 768));
+  const i32x2 v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + STEP));
+  const i32x2 v2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 2 * STEP));
+  const i32x2 v3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2*)(p + 3 * STEP));
   const i32x4 lo = __builtin_shufflevector(v0, v1, 0, 1, 2, 3), hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3);
   return (i32x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
   constexpr int DPART = 4 * 64 * 64;                        // f16 [4 co-tiles][64 pix][32 co]
   constexpr int D8IMG = 4 * 64 * 32, D8 = 2 * D8IMG;        // e5m2 [dyl' | dyh'][4 co-tiles][64 pix][32 co]
   constexpr int XPART = 2 * NXP * 64;                       // f16 [2 ci-tiles][160 pix][32 ci]
-  constexpr int X8IMG = 2 * NXP * 32, X8 = 2 * X8IMG;       // e5m2 [xh' | xl'][2 ci-tiles][160 pix][32 ci]
+  constexpr int X8 = 2 * NXP * 64;                          // e5m2 [2 ci-tiles][160 pix][4 octets][xl' x 8 | xh' x 8]: the
+                                                            // records' second halves as they are (16-byte LDS-DMA granules)
   constexpr int OFF_D8 = DPART, OFF_X = DPART + D8, OFF_X8 = OFF_X + XPART;
   constexpr int BUF = OFF_X8 + X8;                          // 72 KiB, two of them
   // TWO arrays, and a tile loop unrolled by two so that every tile body reads one array and DMAs into the other by
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
   const size_t out_plane = (size_t)a.Hout * a.Wout;
   // lane offsets of the transposed fragment reads (derivations: conv_f16c8.hip), RECOMPUTED where a pass starts from a
   // laundered lane id (see lane_now below): as loop-long constants they were the registers the compiler spilled
-  struct LaneC { int lpart, lchunk, sa0, sa1, l8; };
+  struct LaneC { int lpart, lchunk, sa0, sa1, l8, lx8; };
   auto lane_consts = [&]() __attribute__((always_inline)) {
     unsigned l = threadIdx.x & 63u;
     asm volatile("" : "+v"(l));
@@ -103,7 +108,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
     c.lchunk = 4 * (g_ & 1) + lp_;
     c.sa0 = c.lpart * 64 + ((c.lchunk ^ ((c.lpart >> 1) & 7)) * 8);
     c.sa1 = (c.lpart + 4) * 64 + ((c.lchunk ^ (((c.lpart + 4) >> 1) & 7)) * 8);
-    c.l8 = (li_ >> 1) * 32 + ((g_ & 1) * 2 + (li_ & 1)) * 8 + (g_ >> 1) * 0;
+    c.l8 = (li_ >> 1) * 32 + ((g_ & 1) * 2 + (li_ & 1)) * 8;                 // dY fp8 images: [pixel][32 channel bytes]
+    // X fp8 image: source lane (j, p) of group G points at pixel P + j, octet 2 (G & 1) + p, half G >> 1 (K block 0 = xh',
+    // the record's LAST 8 bytes; K block 1 = xl')
+    c.lx8 = (li_ >> 1) * 64 + ((g_ & 1) * 2 + (li_ & 1)) * 16 + ((g_ >> 1) ? 0 : 8);
     return c;
   };
   auto sx_of = [&](const LaneC& c, int res) __attribute__((always_inline)) {
@@ -209,8 +217,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
   // the hardware writes zeros.
   const unsigned OOR = 0x80000000u;
   const unsigned xspan = (unsigned)(8 * in_plane * 32);
-  const int f16_hf = wave >> 1, f16_m0 = 5 * (wave & 1);      // this wave's pieces of the f16 image
-  const int f8_img = wave >> 1, f8_hf = wave & 1;             // this wave's fp8 image and ci-tile
+  const int dma_hf = wave >> 1, dma_m0 = 5 * (wave & 1);      // this wave's ci-tile and pieces (of both images)
   // (lane-derived constants are RECOMPUTED at their use from a laundered lane id: kept in registers across the tile loop
   // they were spilled and reloaded through scratch, each reload behind an s_waitcnt vmcnt(0) that drained the DMAs)
   auto lane_now = [&]() __attribute__((always_inline)) {
@@ -218,44 +225,25 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
     asm volatile("" : "+v"(l));
     return l;
   };
-  // piece k (0..4) of the f16 image, piece m (0..19) of the fp8 image; buf = byte offset of the target buffer
-  auto dma_x16 = [&](const __amdgpu_buffer_rsrc_t srd, const TileC& tc, unsigned char* wb, auto kc) __attribute__((always_inline)) {
+  // piece k (0..4) of this wave: 16 halo pixels x 4 octets x 16 bytes = 1 KiB of the f16 image (records' first halves,
+  // 16-byte unit = octet ^ ((pixel >> 1) & 3)) and 1 KiB of the fp8 image (second halves, unit = octet).  An LDS-DMA
+  // instruction costs ~100 issue cycles beside MFMAs: 10 per wave and tile, not the 25 a 4-byte-granule fp8 image took.
+  auto dma_x = [&](const __amdgpu_buffer_rsrc_t srd, const TileC& tc, unsigned char* wb, auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
-    const int m = f16_m0 + k;                                  // uniform
-    const unsigned ln = lane_now(), l16u = ln & 3u, l16p = ln >> 2;
-    const unsigned pix = 16u * (unsigned)m + l16p;
+    const int m = dma_m0 + k;                                  // uniform
+    const unsigned ln = lane_now(), lu = ln & 3u, lp = ln >> 2;
+    const unsigned pix = 16u * (unsigned)m + lp;
     const unsigned rr = (pix * 205u) >> 13, cc = pix - 40u * rr;   // pix / 40 for pix < 160
     const int vy = tc.oy0 - 1 + (int)rr, vx = tc.ox0 - 1 + (int)cc;
     const bool ok = (cc < (unsigned)XWV) & ((unsigned)vy < (unsigned)a.Hin) & ((unsigned)vx < (unsigned)a.Win);
-    const unsigned octr = l16u ^ ((pix >> 1) & 3u);
-    const unsigned vo = ((octr * (unsigned)in_plane + (unsigned)(vy * a.Win + vx)) * 32u & (ok ? ~0u : 0u)) | (ok ? 0u : OOR);
+    const unsigned pixoff = (unsigned)(vy * a.Win + vx);
+    const unsigned v16 = ok ? ((lu ^ ((pix >> 1) & 3u)) * (unsigned)in_plane + pixoff) * 32u : OOR;
+    const unsigned v8 = ok ? (lu * (unsigned)in_plane + pixoff) * 32u + 16u : OOR;
+    const int soff = dma_hf * 4 * (int)in_plane * 32;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        srd, (__attribute__((address_space(3))) void*)(wb + OFF_X + f16_hf * (NXP * 64) + m * 1024), 16, (int)vo,
-        f16_hf * 4 * (int)in_plane * 32, 0, 0);
-  };
-  // fp8 pieces: a lane's offset = vb8 (set per tile: its octet / byte part + the halo origin + its pixel of the piece)
-  // + a scalar per piece; validity = the piece's row (scalar) and the lane's column in one of five column groups
-  unsigned vb8 = 0, colm = 0;   // colm bit cg: column 8 cg + (lane >> 3) is a valid image column of this tile
-  auto dma_x8_setup = [&](const TileC& tc) __attribute__((always_inline)) {
-    const unsigned ln = lane_now();
-    const int l8p = (int)(ln >> 3);
-    vb8 = ((ln >> 1) & 3u) * (unsigned)in_plane * 32u + (f8_img ? 16u : 24u) + 4u * (ln & 1u) +
-          (unsigned)((tc.oy0 - 1) * a.Win + tc.ox0 - 1 + l8p) * 32u;
-    colm = 0;
-#pragma unroll
-    for (int cg = 0; cg < 5; ++cg) {
-      const int cc = 8 * cg + l8p;
-      colm |= (((cc < XWV) & ((unsigned)(tc.ox0 - 1 + cc) < (unsigned)a.Win)) ? 1u : 0u) << cg;
-    }
-  };
-  auto dma_x8 = [&](const __amdgpu_buffer_rsrc_t srd, const TileC& tc, unsigned char* wb, auto mc) __attribute__((always_inline)) {
-    constexpr int m = decltype(mc)::value, rr = m / 5, cg = m % 5;          // 8 pixels of ONE halo row
-    const bool rowok = (unsigned)(tc.oy0 - 1 + rr) < (unsigned)a.Hin;        // uniform
-    const bool ok = rowok & ((colm >> cg) & 1u);
-    const unsigned vo = ok ? vb8 + (unsigned)((rr * a.Win + 8 * cg) * 32) : OOR;
+        srd, (__attribute__((address_space(3))) void*)(wb + OFF_X + dma_hf * (NXP * 64) + m * 1024), 16, (int)v16, soff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        srd, (__attribute__((address_space(3))) void*)(wb + OFF_X8 + f8_img * X8IMG + f8_hf * (NXP * 32) + m * 256), 4,
-        (int)vo, f8_hf * 4 * (int)in_plane * 32, 0, 0);
+        srd, (__attribute__((address_space(3))) void*)(wb + OFF_X8 + dma_hf * (NXP * 64) + m * 1024), 16, (int)v8, soff, 0, 0);
   };
   auto x_srd = [&](const TileC& tc) __attribute__((always_inline)) {
     return __builtin_amdgcn_make_buffer_rsrc(
@@ -265,12 +253,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
   // staging work of tap slot s (0..26) of row 0 (issue) / row 1 (commit)
   auto issue_slot = [&](const __amdgpu_buffer_rsrc_t srd, const TileC& tc, unsigned char* buf, auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
-    if constexpr (s == 0) dma_x8_setup(tc);
-    if constexpr (s < 5) dma_x16(srd, tc, buf, sc);
-    if constexpr (s < 10) {
-      dma_x8(srd, tc, buf, std::integral_constant<int, 2 * s>{});
-      dma_x8(srd, tc, buf, std::integral_constant<int, 2 * s + 1>{});
-    }
+    if constexpr (s < 10 && (s & 1) == 0) dma_x(srd, tc, buf, std::integral_constant<int, s / 2>{});
     if constexpr (s >= 12 && s < 20) issue_dy(tc, std::integral_constant<int, s - 12>{});
   };
   auto commit_slot = [&](unsigned char* nbase, auto sc) __attribute__((always_inline)) {
@@ -285,8 +268,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
   // fragments; the A fragments of a pass two slots before its first slot); `work(slot)` is the slot's staging slice.
   i32x8 a8[2];            // fp8 pass: dyl' | dyh' of the wave's two co-tiles
   f16x8 ah[2][2];         // f16 k-step kk: dy_hi of the two co-tiles
-  i32x8 bring[3];         // fp8 B fragments of slots s, s + 1, s + 2
-  f16x8 bring16[3];       // f16 B fragments
+  constexpr int AHEAD = 4, RING = AHEAD + 1;   // fragments are requested AHEAD slots before their MFMAs
+  i32x8 bring[RING];      // fp8 B fragments of slots s .. s + AHEAD
+  f16x8 bring16[RING];    // f16 B fragments
   int o8a = 0, o8b = 0;   // lane offsets of the fp8 pass, computed where its first fragment is requested
   int qo[6];              // lane offsets of the six f16 window starts (kx, pixel-row half), computed once per row
   // requests of slot s (0..26) of output row `row` of the buffer at `base`; s >= 27 wraps into row + 1 of the SAME buffer
@@ -299,11 +283,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
           const LaneC c = lane_consts();
           const int g_ = (int)(lane_now() >> 5);   // K block of the destination lanes = image of the source lanes
           o8a = OFF_D8 + g_ * D8IMG + ct * (64 * 32) + c.l8;      // dyl' (h = 0) | dyh' (h = 1)
-          o8b = OFF_X8 + g_ * X8IMG + cih * (NXP * 32) + c.l8;    // xh'  (h = 0) | xl'  (h = 1)
+          o8b = OFF_X8 + cih * (NXP * 64) + c.lx8;                // xh'  (h = 0) | xl'  (h = 1)
           a8[0] = tr8(base + o8a + row * (32 * 32));
           a8[1] = tr8(base + o8a + (64 * 32) + row * (32 * 32));
         }
-        bring[s_ % 3] = tr8(base + o8b + ((row + ky) * XW + kx) * 32);
+        bring[(27 * decltype(rowc)::value + s_) % RING] = tr8<512>(base + o8b + ((row + ky) * XW + kx) * 64);
       } else {
         constexpr int kk = kind - 1, ks = 2 * row + kk;
         if constexpr (t == 0) {
@@ -321,29 +305,27 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
           }
         }
         const unsigned char* xw = base + OFF_X + cih * (NXP * 64) + (row * XW + 16 * kk) * 64;   // uniform
-        bring16[s_ % 3] = tr16(xw + qo[kx] + ky * (XW * 64), xw + qo[3 + kx] + ky * (XW * 64));
+        bring16[(27 * decltype(rowc)::value + s_) % RING] = tr16(xw + qo[kx] + ky * (XW * 64), xw + qo[3 + kx] + ky * (XW * 64));
       }
     }
   };
   // first: the row's slots 0 and 1 are requested here (tile start: nothing could be requested across the barrier)
   auto row_pass = [&](const unsigned char* base, auto rowc, auto&& work) __attribute__((always_inline)) {
     constexpr int row = decltype(rowc)::value;
-    if constexpr (row == 0) {
-      request(base, rowc, std::integral_constant<int, 0>{});
-      request(base, rowc, std::integral_constant<int, 1>{});
-    }
+    if constexpr (row == 0)
+      static_for<0, AHEAD>([&](auto sc) __attribute__((always_inline)) { request(base, rowc, sc); });
     static_for<0, 27>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value, kind = s / 9, t = s % 9;
       __builtin_amdgcn_sched_barrier(0);
-      request(base, rowc, std::integral_constant<int, s + 2>{});
-      work(sc);
+      if constexpr (!(EOVAE_WG4_ABL & 2)) request(base, rowc, std::integral_constant<int, s + AHEAD>{});
+      if constexpr (!(EOVAE_WG4_ABL & 1)) work(sc);
       // 18 accumulator tuples, 16 fit the AGPRs -- and hipcc selects the AGPR form for every MFMA builtin, so with all
       // 18 behind builtins it moved 16 registers AGPR <-> VGPR around EVERY MFMA (s_nop 13 + 32 copies each: 3.5 x
       // slower than the 8-wave kernel).  The two tuples of tap 8 are therefore VGPR-form MFMAs in inline assembly:
       // operands come from LDS reads the compiler waits for, the scale registers are loop constants, and the results
       // are next read by the same instruction eight slots later (no wait states needed in between).
       if constexpr (kind == 0) {
-        const i32x8 b8 = bring[(s + 27 * row) % 3];
+        const i32x8 b8 = bring[(s + 27 * row) % RING];
         if constexpr (t < NT - 1) {
           acc[t][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[0], b8, acc[t][0], 1 /* A: e5m2 */, 1 /* B: e5m2 */,
                                                                      0, sc_a, 0, sc_b);
@@ -357,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
                        : "+v"(accv1) : "v"(a8[1]), "v"(b8), "v"(sc_av), "v"(sc_bv));
         }
       } else {
-        const f16x8 bh = bring16[(s + 27 * row) % 3];
+        const f16x8 bh = bring16[(s + 27 * row) % RING];
         if constexpr (t < NT - 1) {
           acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kind - 1][0], bh, acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kind - 1][1], bh, acc[t][1], 0, 0, 0);
@@ -401,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
     row_pass(rb, std::integral_constant<int, 0>{}, [&](auto sc) __attribute__((always_inline)) { issue_slot(srd, tn, wb, sc); });
     row_pass(rb, std::integral_constant<int, 1>{}, [&](auto sc) __attribute__((always_inline)) { commit_slot(wb, sc); });
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    if constexpr (!(EOVAE_WG4_ABL & 4)) __syncthreads();
     ++k;
   };
   for (int pr = 0; pr < (cnt + 1) / 2; ++pr) {
