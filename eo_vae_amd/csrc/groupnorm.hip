@@ -5,10 +5,12 @@
 // statistics are a pure streaming reduction: float4 loads, per-thread fp32 partials, wave64
 // shuffle trees, cross-wave/cross-block combine in double.  Memory-bound (HBM roofline).
 #include "eovae_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int GN_SPLIT_ELEMS = 16384;  // elements per stats block
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 
@@ -310,6 +312,271 @@ __global__ __launch_bounds__(256) void amax_fold_kernel(const float* __restrict_
   if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// backward, ONE pass over the activation (12 B per element instead of the 20 of reduce + apply):
+// a persistent grid of at most TWO 256-thread workgroups per CU.  A TEAM of T workgroups owns one (image, group) slab
+// at a time; each member loads its slice of x and dy ONCE into registers (V float4 of each per thread), publishes its
+// partial sums (s1 = sum dz, s2 = sum dz * xhat), waits until the whole team has published, folds the team's partials
+// into the group means m1, m2 and writes dx from the registers.  The slab is never re-read, so nothing depends on what
+// a cache still holds.  Two workgroups per CU: while one computes or waits for its team, the other one streams.
+//
+// Hand-off between workgroups (MI355X_MICROARCH.md, cross-workgroup visibility): a member's contribution to the group
+// means travels as ONE 16-byte granule {sum s1 gamma, sum s2 gamma, 64-bit token} stored and polled with sc0 sc1 --
+// the granule validates itself, so no fence, no flag and no counter to reset; the token is unique per call (host
+// counter), stale granules of earlier calls never match.  Every workgroup of the grid is resident (grid <= 2 x CUs;
+// two workgroups of <= 256 VGPRs and 0.3 KiB of LDS per CU fit by construction) and publishes before it waits, so the
+// wait ends; it is bounded all the same (4e9 shader clocks, about 2 s): on a time-out the workgroup records the token
+// in `err`, and the finalize kernel poisons dgamma / dbeta with NaN.
+// The per-channel partials (for dgamma / dbeta) are plain stores, read by the finalize kernel after the launch.
+// The NEXT slab's loads are issued at the top of a round, before this slab's arithmetic.
+constexpr int GNF_NT = 256;             // threads per workgroup
+constexpr int GNF_UNIT = GNF_NT * 4;
+// resident workgroups per CU by slice size (register budget: V = 8 needs ~220 VGPRs, V = 4 ~140, V <= 2 ~100)
+constexpr int gnf_wg_per_cu(int V) { return V >= 8 ? 2 : V == 4 ? 3 : 4; }
+//    // elements one float4 per thread covers: the unit of the per-channel partials
+struct GnBwdFArgs {
+  const float *x, *dy, *gamma, *beta, *stats, *dx_add;
+  float* dx;
+  i32x4* team;             // [N*G][T] member granules
+  float2* part;            // [N*G][T*V] (s1, s2) of the slab's elements [UNIT j, UNIT j + UNIT)
+  float* amax_part;        // [grid][4] per-wave max |dx| (or null)
+  unsigned long long* err;
+  unsigned long long token;
+  int C, HW, cpg, G, T, nteams, NG;
+  float inv_count;
+  int nosync;              // timing experiments only (EOVAE_GN_BWD_NOSYNC=1): skip the team wait -- WRONG results
+};
+
+// (taking the int by VALUE matters: __builtin_bit_cast applied to the element expression gv[1] itself read element 0)
+__device__ __forceinline__ float bits_f(int b) { return __builtin_bit_cast(float, b); }
+__device__ __forceinline__ void granule_store(i32x4* p, float s1, float s2, unsigned long long tok) {
+  i32x4 v;
+  v[0] = __builtin_bit_cast(int, s1);
+  v[1] = __builtin_bit_cast(int, s2);
+  v[2] = (int)(unsigned)tok;
+  v[3] = (int)(unsigned)(tok >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ i32x4 granule_load(const i32x4* p) {
+  i32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <bool SILU, bool ADD, int V>
+__global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(GnBwdFArgs a) {
+  constexpr int SE = V * GNF_UNIT;                   // elements of one member's slice
+  constexpr int NW = GNF_NT / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int team = blockIdx.x / a.T, member = blockIdx.x % a.T;
+  const size_t slab = (size_t)a.cpg * a.HW;
+  __shared__ double red[NW][2 * V];
+  __shared__ float gmean[2];
+  float4 xr[V], dr[V], xn[V], dn[V], ar[V];
+  float amax = 0.f;
+
+  auto slice_ptr = [&](const float* p, int s) { return p + (size_t)s * slab + (size_t)member * SE + 4 * tid; };
+  auto prefetch = [&](int s) __attribute__((always_inline)) {
+    if (s < a.NG) {
+      const float* px = slice_ptr(a.x, s);
+      const float* pd = slice_ptr(a.dy, s);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        xn[v] = *reinterpret_cast<const float4*>(px + v * GNF_UNIT);
+        dn[v] = *reinterpret_cast<const float4*>(pd + v * GNF_UNIT);
+      }
+    }
+  };
+
+  int s = team;
+  prefetch(s);
+  for (; s < a.NG; s += a.nteams) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) { xr[v] = xn[v]; dr[v] = dn[v]; }
+    prefetch(s + a.nteams);   // in flight during this slab's arithmetic, hand-off and stores
+    if (ADD) {
+      const float* pa = slice_ptr(a.dx_add, s);
+#pragma unroll
+      for (int v = 0; v < V; ++v) ar[v] = *reinterpret_cast<const float4*>(pa + v * GNF_UNIT);
+    }
+    const int g = s % a.G;
+    const float mean = a.stats[2 * s], rstd = a.stats[2 * s + 1];
+    // ---- partial sums; the registers then hold  A = rstd * gamma * dz  and  B = rstd * xhat  (dx = A - rstd m1 - B m2)
+    float ps1[V], ps2[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = g * a.cpg + (member * SE + v * GNF_UNIT) / a.HW;   // uniform: UNIT divides HW
+      const float gm = a.gamma[c], bt = a.beta[c];
+      float s1 = 0.f, s2 = 0.f;
+      auto term = [&](float& xv, float& dv) __attribute__((always_inline)) {
+        const float xh = (xv - mean) * rstd;
+        float dz = dv;
+        if (SILU) {
+          const float z = xh * gm + bt;
+          const float sg = 1.f / (1.f + __expf(-z));
+          dz *= sg * (1.f + z * (1.f - sg));
+        }
+        s1 += dz;
+        s2 += dz * xh;
+        dv = rstd * gm * dz;
+        xv = rstd * xh;
+      };
+      term(xr[v].x, dr[v].x); term(xr[v].y, dr[v].y); term(xr[v].z, dr[v].z); term(xr[v].w, dr[v].w);
+      ps1[v] = s1;
+      ps2[v] = s2;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const double d1 = wave_sum_d((double)ps1[v]), d2 = wave_sum_d((double)ps2[v]);
+      if (lane == 0) { red[wave][2 * v] = d1; red[wave][2 * v + 1] = d2; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // ---- this member's partials: per unit (plain stores, for dgamma / dbeta) and folded with gamma (the granule)
+      double t1 = 0, t2 = 0;
+      if (lane < V) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t1 += red[w][2 * lane]; t2 += red[w][2 * lane + 1]; }
+        a.part[(size_t)s * a.T * V + member * V + lane] = make_float2((float)t1, (float)t2);
+        const float gmv = a.gamma[g * a.cpg + (member * SE + lane * GNF_UNIT) / a.HW];
+        t1 *= gmv;
+        t2 *= gmv;
+      }
+      t1 = wave_sum_d(t1);
+      t2 = wave_sum_d(t2);
+      i32x4* tg = a.team + (size_t)s * a.T;
+      if (lane == 0) granule_store(tg + member, (float)t1, (float)t2, a.token);
+      // ---- wait for the team, fold its granules (fixed order: deterministic)
+      double m1 = 0, m2 = 0;
+      const unsigned long long t0 = __builtin_readcyclecounter();   // s_memtime
+      bool late = false;
+      for (int j = lane; j < (a.nosync ? 0 : a.T); j += 64) {
+        i32x4 gv;
+        for (;;) {
+          gv = granule_load(tg + j);
+          const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
+          if (tk == a.token) break;
+          if (__builtin_readcyclecounter() - t0 > 4000000000ull) { late = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        m1 += (double)bits_f(gv[0]);
+        m2 += (double)bits_f(gv[1]);
+      }
+      if (late) *a.err = a.token;
+      m1 = wave_sum_d(m1);
+      m2 = wave_sum_d(m2);
+      if (lane == 0) {
+        gmean[0] = (float)(m1 * (double)a.inv_count);
+        gmean[1] = (float)(m2 * (double)a.inv_count);
+      }
+    }
+    __syncthreads();
+    const float k1 = rstd * gmean[0], m2f = gmean[1];
+    float* po = a.dx + (size_t)s * slab + (size_t)member * SE + 4 * tid;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float4 o;
+      o.x = dr[v].x - k1 - xr[v].x * m2f;
+      o.y = dr[v].y - k1 - xr[v].y * m2f;
+      o.z = dr[v].z - k1 - xr[v].z * m2f;
+      o.w = dr[v].w - k1 - xr[v].w * m2f;
+      if (ADD) { o.x += ar[v].x; o.y += ar[v].y; o.z += ar[v].z; o.w += ar[v].w; }
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      *reinterpret_cast<float4*>(po + v * GNF_UNIT) = o;
+    }
+  }
+  if (a.amax_part) {
+    amax = wave_max(amax);
+    if (lane == 0) a.amax_part[blockIdx.x * NW + wave] = amax;
+  }
+}
+
+// after the fused kernel: dgamma / dbeta from the per-unit partials (fixed order), max |dx| folded by block 0
+__global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2* __restrict__ part,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    const float* __restrict__ amax_part, int n_part,
+                                                                    unsigned* __restrict__ amax_bits,
+                                                                    const unsigned long long* __restrict__ err,
+                                                                    unsigned long long token, int N, int C, int HW, int cpg) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const int G = C / cpg, g = c / cpg, cj = c % cpg, per = HW / GNF_UNIT;
+    const size_t slab_units = (size_t)cpg * per;
+    double a1 = 0, a2 = 0;
+    for (int n = 0; n < N; ++n) {
+      const float2* p = part + ((size_t)n * G + g) * slab_units + (size_t)cj * per;
+      for (int j = 0; j < per; ++j) {
+        const float2 v = p[j];
+        a1 += (double)v.x;
+        a2 += (double)v.y;
+      }
+    }
+    const bool bad = *err == token;
+    dbeta[c] = bad ? __builtin_nanf("") : (float)a1;
+    dgamma[c] = bad ? __builtin_nanf("") : (float)a2;
+  }
+  if (blockIdx.x == 0 && amax_bits) {
+    __shared__ float wm[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) m = fmaxf(m, amax_part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+      *amax_bits = (m > 0.f && m < 3.0e38f) ? __builtin_bit_cast(unsigned, m) : 0u;
+    }
+  }
+}
+
+// plan of the fused backward for one shape: V float4 per thread, team size T; T = 0 when the shape is not eligible
+struct GnBwdPlan { int V, T, nteams, grid; };
+int g_gn_bwd_fused = -1;   // -1: take EOVAE_GN_BWD_FUSED (default on) at first use
+constexpr int GNF_MAX_GRID = 1024;   // 4 workgroups x 256 CUs
+GnBwdPlan gn_bwd_plan(int N, int C, int HW, int G) {
+  GnBwdPlan p = {0, 0, 0, 0};
+  static int n_cu = 0;
+  int& enabled = g_gn_bwd_fused;
+  if (enabled < 0) {
+    const char* e = getenv("EOVAE_GN_BWD_FUSED");
+    enabled = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+  }
+  if (n_cu == 0) {
+    n_cu = -1;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+  }
+  if (!enabled || n_cu <= 0 || HW % GNF_UNIT != 0) return p;
+  static const int vmax = getenv("EOVAE_GN_BWD_VMAX") ? atoi(getenv("EOVAE_GN_BWD_VMAX")) : 8;
+  const size_t slab = (size_t)(C / G) * HW;
+  const size_t q = slab / GNF_UNIT;
+  const int V = (q % 8 == 0 && vmax >= 8) ? 8 : (q % 4 == 0 && vmax >= 4) ? 4 : (q % 2 == 0 && vmax >= 2) ? 2 : 1;
+  int slots = gnf_wg_per_cu(V) * n_cu;        // resident workgroups
+  if (slots > GNF_MAX_GRID) slots = GNF_MAX_GRID;
+  const size_t T = q / V;
+  if (T > (size_t)slots) return p;
+  p.V = V;
+  p.T = (int)T;
+  const int NG = N * G;
+  p.nteams = slots / p.T < NG ? slots / p.T : NG;
+  p.grid = p.nteams * p.T;
+  return p;
+}
+// workspace of the fused backward: member granules | per-unit partials | per-wave maxima | time-out word
+struct GnBwdWs { size_t team, part, amax, err, total; };
+GnBwdWs gn_bwd_ws(int N, int C, int HW, int G) {
+  GnBwdWs w = {0, 0, 0, 0, 0};
+  if (HW % GNF_UNIT != 0) return w;
+  const size_t units = (size_t)N * C * (HW / GNF_UNIT);   // >= N*G*T members
+  w.team = 0;
+  w.part = units * 16;
+  w.amax = w.part + units * 8;
+  w.err = w.amax + (size_t)GNF_MAX_GRID * 4 * sizeof(float);
+  w.total = w.err + 64;
+  return w;
+}
+
 int nsplit_for(size_t gsize) {
   int ns = (int)((gsize + GN_SPLIT_ELEMS - 1) / GN_SPLIT_ELEMS);
   if (ns < 1) ns = 1;
@@ -336,6 +603,8 @@ size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G) {
   size_t fwd = (size_t)N * G * nsplit_for(gsize) * 2 * sizeof(double);
   size_t bwd = (size_t)N * C * 2 * sizeof(double) + (size_t)N * G * 2 * sizeof(float) +
                (size_t)N * C * chunks_for(HW) * 4 * sizeof(float);   // + per-wave max|dx| partials
+  const size_t fused = gn_bwd_ws(N, C, HW, G).total;
+  if (fused > bwd) bwd = fused;
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -392,6 +661,19 @@ int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* be
   return EOVAE_OK;
 }
 
+// switch between the one-pass (fused, default) and the two-pass GroupNorm backward: on = 0 / 1 / 2 sets it (2 = also
+// where the two-pass kernels measured faster), anything else only queries; returns the setting now in force (-1 = not decided yet: EOVAE_GN_BWD_FUSED at first use).
+// eovae_gn_silu_bwd takes the fused kernel when it is on AND the shape allows it (HW a multiple of 1024, team <= 2 x CUs).
+int eovae_gn_bwd_fused(int on) {
+  if (on == 0 || on == 1 || on == 2) g_gn_bwd_fused = on;
+  return g_gn_bwd_fused;
+}
+// 1 when eovae_gn_silu_bwd would take the fused kernel for this shape
+int eovae_gn_bwd_fused_eligible(int N, int C, int HW, int G) {
+  if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
+  return gn_bwd_plan(N, C, HW, G).T > 0 ? 1 : 0;
+}
+
 // dx (+= dx_add if given), dgamma, dbeta from the saved stats
 int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
                       const float* stats, const float* dx_add, float* dx, float* dgamma,
@@ -402,6 +684,40 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
   EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "gn_silu_bwd: C=%d G=%d", C, G);
   hipStream_t st = (hipStream_t)stream;
   const int cpg = C / G;
+  GnBwdPlan plan = gn_bwd_plan(N, C, HW, G);
+  // measured (profiles/r03l_gn_bwd_ab.log): with 4 channels per group and no skip gradient to fold in, the two-pass
+  // kernels are 2 % faster (their second read of a 1 MiB slab is cheap, the hand-off is not); everywhere else the
+  // one-pass kernel wins by 1.00-1.36 x.  EOVAE_GN_BWD_FUSED=2 (or eovae_gn_bwd_fused(2)) forces it for every shape.
+  if (plan.T > 0 && g_gn_bwd_fused != 2 && !dx_add && cpg < 8) plan.T = 0;
+  if (plan.T > 0) {
+    static unsigned long long calls = 0;   // token: a NaN-pattern prefix no partial sum carries + the call number
+    GnBwdFArgs a;
+    a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.stats = stats; a.dx_add = dx_add; a.dx = dx;
+    const GnBwdWs w = gn_bwd_ws(N, C, HW, G);
+    a.team = (i32x4*)((char*)ws + w.team);
+    a.part = (float2*)((char*)ws + w.part);
+    a.amax_part = dx_amax_bits ? (float*)((char*)ws + w.amax) : nullptr;
+    a.err = (unsigned long long*)((char*)ws + w.err);
+    a.token = 0xFFF8E0A000000000ull | (++calls & 0xFFFFFFFFFull);
+    a.C = C; a.HW = HW; a.cpg = cpg; a.G = G; a.T = plan.T; a.nteams = plan.nteams; a.NG = N * G;
+    a.inv_count = (float)(1.0 / ((double)cpg * HW));
+    static const int nosync = getenv("EOVAE_GN_BWD_NOSYNC") ? atoi(getenv("EOVAE_GN_BWD_NOSYNC")) : 0;
+    a.nosync = nosync;
+    void (*k)(GnBwdFArgs) = nullptr;
+#define EOVAE_GN_PICK(S, A)                                                                         \
+    k = plan.V == 8 ? gn_bwd_fused_kernel<S, A, 8> : plan.V == 4 ? gn_bwd_fused_kernel<S, A, 4>     \
+      : plan.V == 2 ? gn_bwd_fused_kernel<S, A, 2> : gn_bwd_fused_kernel<S, A, 1>
+    if (silu && dx_add) EOVAE_GN_PICK(true, true);
+    else if (silu) EOVAE_GN_PICK(true, false);
+    else if (dx_add) EOVAE_GN_PICK(false, true);
+    else EOVAE_GN_PICK(false, false);
+#undef EOVAE_GN_PICK
+    hipLaunchKernelGGL(k, dim3(plan.grid), dim3(GNF_NT), 0, st, a);
+    hipLaunchKernelGGL(gn_bwd_fused_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, a.part, dgamma, dbeta,
+                       a.amax_part, plan.grid * (GNF_NT / 64), dx_amax_bits, a.err, a.token, N, C, HW, cpg);
+    EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd (fused)");
+    return EOVAE_OK;
+  }
   double* sums = (double*)ws;
   float* gm = (float*)(sums + (size_t)N * C * 2);
   if (silu)

@@ -47,6 +47,8 @@ SIGNATURES = {
     'eovae_gn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'eovae_gn_bwd_fused': (_i, [_i]),
+    'eovae_gn_bwd_fused_eligible': (_i, [_i, _i, _i, _i]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
     'eovae_softmax_bwd_rows': (_i, [_p, _p, _ll, _i, _p]),

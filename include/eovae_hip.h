@@ -156,6 +156,13 @@ size_t eovae_gn_workspace_bytes(int N, int C, int HW, int G);
 int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                       const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
                       void* stream);
+/* One-pass GroupNorm backward (a persistent cooperative kernel: x and dy are read once, 12 B per element instead of 20).
+ * eovae_gn_bwd_fused(0 / 1 / 2) switches it off / on / on for every eligible shape (1 leaves the shapes where the
+ * two-pass kernels measured faster -- 4 channels per group, no dx_add -- to them), any other value only queries; the return value is the setting in
+ * force (-1 = undecided: environment EOVAE_GN_BWD_FUSED, default on, is read at first use).
+ * eovae_gn_bwd_fused_eligible: 1 when eovae_gn_silu_bwd takes that kernel for the shape (HW % 1024 == 0, team <= 2 x CUs). */
+int eovae_gn_bwd_fused(int on);
+int eovae_gn_bwd_fused_eligible(int N, int C, int HW, int G);
 /* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C]; dx_amax_bits (nullable, device): receives the
  * float bits of max|dx| -- the pre-scale input of eovae_conv3x3_f16c8_fwd's data-gradient calls, produced
  * here for free instead of by a separate eovae_absmax_bits pass over dx */
