@@ -6,6 +6,9 @@
 // shuffle trees, cross-wave/cross-block combine in double.  Memory-bound (HBM roofline).
 #include "eovae_common.h"
 #include <stdlib.h>
+#include <unistd.h>
+#include <chrono>
+#include <random>
 
 namespace {
 
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(256) void amax_fold_kernel(const float* __restrict_
 //
 // Hand-off between workgroups (MI355X_MICROARCH.md, cross-workgroup visibility): a member's contribution to the group
 // means travels as ONE 16-byte granule {sum s1 gamma, sum s2 gamma, 64-bit token} stored and polled with sc0 sc1 --
-// the granule validates itself, so no fence, no flag and no counter to reset; the token is unique per call (host
-// counter), stale granules of earlier calls never match.  Every workgroup of the grid is resident (grid <= 2 x CUs;
+// the granule validates itself, so no fence, no flag and no counter to reset; the token is unique per call and per
+// process (64 pseudo-random bits), stale granules of earlier calls or of other processes never match.  Every workgroup of the grid is resident (grid <= 2 x CUs;
 // two workgroups of <= 256 VGPRs and 0.3 KiB of LDS per CU fit by construction) and publishes before it waits, so the
 // wait ends; it is bounded all the same (4e9 shader clocks, about 2 s): on a time-out the workgroup records the token
 // in `err`, and the finalize kernel poisons dgamma / dbeta with NaN.
@@ -341,6 +344,7 @@ struct GnBwdFArgs {
   float2* part;            // [N*G][T*V] (s1, s2) of the slab's elements [UNIT j, UNIT j + UNIT)
   float* amax_part;        // [grid][4] per-wave max |dx| (or null)
   unsigned long long* err;
+  unsigned* ticket;        // logical workgroup ids are handed out in order of arrival (see the kernel)
   unsigned long long token;
   int C, HW, cpg, G, T, nteams, NG;
   float inv_count;
@@ -368,10 +372,17 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
   constexpr int SE = V * GNF_UNIT;                   // elements of one member's slice
   constexpr int NW = GNF_NT / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int team = blockIdx.x / a.T, member = blockIdx.x % a.T;
-  const size_t slab = (size_t)a.cpg * a.HW;
   __shared__ double red[NW][2 * V];
   __shared__ float gmean[2];
+  __shared__ unsigned ticket_s;
+  // logical id = order of ARRIVAL, not blockIdx: the workgroups that are resident then always hold the lowest ids, i.e.
+  // whole teams (plus at most one partial team), and whole teams finish without waiting for anybody -- the grid makes
+  // progress even when it is NOT fully resident (another process' kernels on the same GPU, e.g. two ranks on one card).
+  if (tid == 0) ticket_s = atomicAdd(a.ticket, 1u) % gridDim.x;
+  __syncthreads();
+  const int bid = (int)ticket_s;
+  const int team = bid / a.T, member = bid % a.T;
+  const size_t slab = (size_t)a.cpg * a.HW;
   float4 xr[V], dr[V], xn[V], dn[V], ar[V];
   float amax = 0.f;
 
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
   }
   if (a.amax_part) {
     amax = wave_max(amax);
-    if (lane == 0) a.amax_part[blockIdx.x * NW + wave] = amax;
+    if (lane == 0) a.amax_part[bid * NW + wave] = amax;
   }
 }
 
@@ -497,8 +508,10 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
                                                                     const float* __restrict__ amax_part, int n_part,
                                                                     unsigned* __restrict__ amax_bits,
                                                                     const unsigned long long* __restrict__ err,
-                                                                    unsigned long long token, int N, int C, int HW, int cpg) {
+                                                                    unsigned long long token, int N, int C, int HW, int cpg,
+                                                                    unsigned* __restrict__ ticket) {
   const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) *ticket = 0u;   // (the kernel takes tickets modulo its grid: a counter left dirty by a failed launch is harmless)
   if (c < C) {
     const int G = C / cpg, g = c / cpg, cj = c % cpg, per = HW / GNF_UNIT;
     const size_t slab_units = (size_t)cpg * per;
@@ -690,15 +703,43 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
   // one-pass kernel wins by 1.00-1.36 x.  EOVAE_GN_BWD_FUSED=2 (or eovae_gn_bwd_fused(2)) forces it for every shape.
   if (plan.T > 0 && g_gn_bwd_fused != 2 && !dx_add && cpg < 8) plan.T = 0;
   if (plan.T > 0) {
-    static unsigned long long calls = 0;   // token: a NaN-pattern prefix no partial sum carries + the call number
+    // token: unique per call AND per process -- the workspace may sit on device memory that an earlier (or a
+    // concurrent) process filled with granules of the very same call sequence, so a plain call counter is not enough
+    // (seen: two ranks sharing one GPU accepted each other's stale granules now and then).  64 random-looking bits:
+    // splitmix64 of (process nonce + call number).
+    static unsigned long long nonce = 0, calls = 0;
+    if (nonce == 0) {
+      std::random_device rd;
+      nonce = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ ((unsigned long long)getpid() << 17) ^
+              (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+      nonce |= 1;
+    }
+    unsigned long long z = nonce + 0x9E3779B97F4A7C15ull * ++calls;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
     GnBwdFArgs a;
     a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.stats = stats; a.dx_add = dx_add; a.dx = dx;
     const GnBwdWs w = gn_bwd_ws(N, C, HW, G);
+    static unsigned* tickets[64] = {nullptr};   // one zero-initialised counter per device, reset by every finalize launch
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      eovae_set_error("gn_silu_bwd: device index");
+      return EOVAE_ERR_LAUNCH;
+    }
+    if (!tickets[dev]) {
+      if (hipMalloc((void**)&tickets[dev], 256) != hipSuccess || hipMemset(tickets[dev], 0, 256) != hipSuccess) {
+        tickets[dev] = nullptr;
+        eovae_set_error("gn_silu_bwd: cannot allocate the ticket counter");
+        return EOVAE_ERR_LAUNCH;
+      }
+    }
+    a.ticket = tickets[dev];
     a.team = (i32x4*)((char*)ws + w.team);
     a.part = (float2*)((char*)ws + w.part);
     a.amax_part = dx_amax_bits ? (float*)((char*)ws + w.amax) : nullptr;
     a.err = (unsigned long long*)((char*)ws + w.err);
-    a.token = 0xFFF8E0A000000000ull | (++calls & 0xFFFFFFFFFull);
+    a.token = z;
     a.C = C; a.HW = HW; a.cpg = cpg; a.G = G; a.T = plan.T; a.nteams = plan.nteams; a.NG = N * G;
     a.inv_count = (float)(1.0 / ((double)cpg * HW));
     static const int nosync = getenv("EOVAE_GN_BWD_NOSYNC") ? atoi(getenv("EOVAE_GN_BWD_NOSYNC")) : 0;
@@ -714,7 +755,7 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
 #undef EOVAE_GN_PICK
     hipLaunchKernelGGL(k, dim3(plan.grid), dim3(GNF_NT), 0, st, a);
     hipLaunchKernelGGL(gn_bwd_fused_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, a.part, dgamma, dbeta,
-                       a.amax_part, plan.grid * (GNF_NT / 64), dx_amax_bits, a.err, a.token, N, C, HW, cpg);
+                       a.amax_part, plan.grid * (GNF_NT / 64), dx_amax_bits, a.err, a.token, N, C, HW, cpg, a.ticket);
     EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd (fused)");
     return EOVAE_OK;
   }

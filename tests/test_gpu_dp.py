@@ -26,6 +26,9 @@ def _build(seed_fill=21):
     from eo_vae_amd.autoencoder import EOFluxVAE
     from eo_vae_amd.losses import EOConsistencyLoss
     from eo_vae_amd.model import Decoder, Encoder
+    from eo_vae_amd.dynamic_conv import prefer_rocblas_for_generator
+    prefer_rocblas_for_generator()   # what the entry points (Trainer, bench.py) do: the workers and the single-process
+    #                                  reference below must multiply the hyper-network's GEMMs with the same BLAS library
     cfg = O.model_cfg(**O.TINY)
     ref = O.build_vae(cfg)
     O.det_fill(ref, seed=seed_fill)
