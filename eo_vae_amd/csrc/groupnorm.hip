@@ -502,7 +502,9 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
   }
 }
 
-// after the fused kernel: dgamma / dbeta from the per-unit partials (fixed order), max |dx| folded by block 0
+// after the fused kernel: dgamma / dbeta from the per-unit partials -- one 64-lane wave per channel, every lane a fixed
+// subset of the (image, unit) partials, butterfly at the end: deterministic, and N x HW/1024 (up to 1024) dependent
+// 8-byte loads per channel no longer sit in ONE thread (32 us per launch, 1.5 ms per step).  Block 0 also folds max |dx|.
 __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2* __restrict__ part,
                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                     const float* __restrict__ amax_part, int n_part,
@@ -510,30 +512,33 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
                                                                     const unsigned long long* __restrict__ err,
                                                                     unsigned long long token, int N, int C, int HW, int cpg,
                                                                     unsigned* __restrict__ ticket) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0) *ticket = 0u;   // (the kernel takes tickets modulo its grid: a counter left dirty by a failed launch is harmless)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + wave;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;   // (tickets are taken modulo the grid: a dirty counter is harmless)
   if (c < C) {
     const int G = C / cpg, g = c / cpg, cj = c % cpg, per = HW / GNF_UNIT;
     const size_t slab_units = (size_t)cpg * per;
     double a1 = 0, a2 = 0;
-    for (int n = 0; n < N; ++n) {
-      const float2* p = part + ((size_t)n * G + g) * slab_units + (size_t)cj * per;
-      for (int j = 0; j < per; ++j) {
-        const float2 v = p[j];
-        a1 += (double)v.x;
-        a2 += (double)v.y;
-      }
+    for (int i = lane; i < N * per; i += 64) {
+      const int n = i / per, j = i - n * per;
+      const float2 v = part[((size_t)n * G + g) * slab_units + (size_t)cj * per + j];
+      a1 += (double)v.x;
+      a2 += (double)v.y;
     }
-    const bool bad = *err == token;
-    dbeta[c] = bad ? __builtin_nanf("") : (float)a1;
-    dgamma[c] = bad ? __builtin_nanf("") : (float)a2;
+    a1 = wave_sum_d(a1);
+    a2 = wave_sum_d(a2);
+    if (lane == 0) {
+      const bool bad = *err == token;
+      dbeta[c] = bad ? __builtin_nanf("") : (float)a1;
+      dgamma[c] = bad ? __builtin_nanf("") : (float)a2;
+    }
   }
   if (blockIdx.x == 0 && amax_bits) {
     __shared__ float wm[4];
     float m = 0.f;
     for (int i = threadIdx.x; i < n_part; i += 256) m = fmaxf(m, amax_part[i]);
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    if (lane == 0) wm[wave] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
       m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
@@ -754,7 +759,7 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
     else EOVAE_GN_PICK(false, false);
 #undef EOVAE_GN_PICK
     hipLaunchKernelGGL(k, dim3(plan.grid), dim3(GNF_NT), 0, st, a);
-    hipLaunchKernelGGL(gn_bwd_fused_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, a.part, dgamma, dbeta,
+    hipLaunchKernelGGL(gn_bwd_fused_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, a.part, dgamma, dbeta,
                        a.amax_part, plan.grid * (GNF_NT / 64), dx_amax_bits, a.err, a.token, N, C, HW, cpg, a.ticket);
     EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd (fused)");
     return EOVAE_OK;
