@@ -86,7 +86,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 7  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):
