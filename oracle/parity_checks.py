@@ -48,7 +48,7 @@ def full_step_errors(prod, g=None):
         'l1_rel_err': rel(l1, g['l1']),
         'kl_max_rel_err': float((kl.detach().double().cpu() - torch.from_numpy(g['kl']).double()).abs().max()
                                 / torch.from_numpy(g['kl']).double().abs().max()),
-        'recon_max_rel_err': float((rec[:, :, ::8, ::8].double().cpu() - ref_r).abs().max() / ref_r.abs().max()),
+        'recon_max_rel_err': float((rec.detach()[:, :, ::8, ::8].double().cpu() - ref_r).abs().max() / ref_r.abs().max()),
     }
     named = dict([('encoder.' + k, p) for k, p in prod.encoder.named_parameters()] +
                  [('decoder.' + k, p) for k, p in prod.decoder.named_parameters()])
