@@ -502,6 +502,158 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
   }
 }
 
+// Software-pipelined form of the kernel above (EOVAE_GN_BWD_PIPE=1): THREE register sets of V float4 pairs -- P (slab
+// s: partial sums published, waiting for its team), Q (slab s + 1: being summed) and N (slab s + 2: loads in flight).
+// The workgroup publishes slab s + 1 BEFORE it waits for slab s, so the hand-off latency of a slab is covered by the
+// arithmetic of the next one.  Same granules, tickets, tokens, partial layout and finalize kernel.
+template <bool SILU, bool ADD, int V>
+__global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_kernel(GnBwdFArgs a) {
+  constexpr int SE = V * GNF_UNIT;
+  constexpr int NW = GNF_NT / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __shared__ double red[NW][2 * V];
+  __shared__ float gmean[2];
+  __shared__ unsigned ticket_s;
+  if (tid == 0) ticket_s = atomicAdd(a.ticket, 1u) % gridDim.x;
+  __syncthreads();
+  const int bid = (int)ticket_s;
+  const int team = bid / a.T, member = bid % a.T;
+  const size_t slab = (size_t)a.cpg * a.HW;
+  float4 xp[V], dp[V], xq[V], dq[V], xn[V], dn[V], ar[V];
+  float amax = 0.f;
+
+  auto slice_ptr = [&](const float* p, int s) { return p + (size_t)s * slab + (size_t)member * SE + 4 * tid; };
+  auto prefetch = [&](int s) __attribute__((always_inline)) {
+    if (s < a.NG) {
+      const float* px = slice_ptr(a.x, s);
+      const float* pd = slice_ptr(a.dy, s);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        xn[v] = *reinterpret_cast<const float4*>(px + v * GNF_UNIT);
+        dn[v] = *reinterpret_cast<const float4*>(pd + v * GNF_UNIT);
+      }
+    }
+  };
+  // Q <- N, sum slab s in Q (Q then holds A = rstd gamma dz, B = rstd xhat), publish this member's granule
+  auto stage = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) { xq[v] = xn[v]; dq[v] = dn[v]; }
+    prefetch(s + a.nteams);
+    const int g = s % a.G;
+    const float mean = a.stats[2 * s], rstd = a.stats[2 * s + 1];
+    float ps1[V], ps2[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = g * a.cpg + (member * SE + v * GNF_UNIT) / a.HW;
+      const float gm = a.gamma[c], bt = a.beta[c];
+      float s1 = 0.f, s2 = 0.f;
+      auto term = [&](float& xv, float& dv) __attribute__((always_inline)) {
+        const float xh = (xv - mean) * rstd;
+        float dz = dv;
+        if (SILU) {
+          const float z = xh * gm + bt;
+          const float sg = 1.f / (1.f + __expf(-z));
+          dz *= sg * (1.f + z * (1.f - sg));
+        }
+        s1 += dz;
+        s2 += dz * xh;
+        dv = rstd * gm * dz;
+        xv = rstd * xh;
+      };
+      term(xq[v].x, dq[v].x); term(xq[v].y, dq[v].y); term(xq[v].z, dq[v].z); term(xq[v].w, dq[v].w);
+      ps1[v] = s1;
+      ps2[v] = s2;
+    }
+    __syncthreads();   // red[] of the previous stage has been read
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const double d1 = wave_sum_d((double)ps1[v]), d2 = wave_sum_d((double)ps2[v]);
+      if (lane == 0) { red[wave][2 * v] = d1; red[wave][2 * v + 1] = d2; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double t1 = 0, t2 = 0;
+      if (lane < V) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t1 += red[w][2 * lane]; t2 += red[w][2 * lane + 1]; }
+        a.part[(size_t)s * a.T * V + member * V + lane] = make_float2((float)t1, (float)t2);
+        const float gmv = a.gamma[g * a.cpg + (member * SE + lane * GNF_UNIT) / a.HW];
+        t1 *= gmv;
+        t2 *= gmv;
+      }
+      t1 = wave_sum_d(t1);
+      t2 = wave_sum_d(t2);
+      if (lane == 0) granule_store(a.team + (size_t)s * a.T + member, (float)t1, (float)t2, a.token);
+    }
+  };
+  // wait for slab s' team, then write dx of slab s from P
+  auto finish = [&](int s) __attribute__((always_inline)) {
+    if (ADD) {
+      const float* pa = slice_ptr(a.dx_add, s);
+#pragma unroll
+      for (int v = 0; v < V; ++v) ar[v] = *reinterpret_cast<const float4*>(pa + v * GNF_UNIT);
+    }
+    if (wave == 0) {
+      const i32x4* tg = a.team + (size_t)s * a.T;
+      double m1 = 0, m2 = 0;
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      bool late = false;
+      for (int j = lane; j < (a.nosync ? 0 : a.T); j += 64) {
+        i32x4 gv;
+        for (;;) {
+          gv = granule_load(tg + j);
+          const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
+          if (tk == a.token) break;
+          if (__builtin_readcyclecounter() - t0 > 4000000000ull) { late = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        m1 += (double)bits_f(gv[0]);
+        m2 += (double)bits_f(gv[1]);
+      }
+      if (late) *a.err = a.token;
+      m1 = wave_sum_d(m1);
+      m2 = wave_sum_d(m2);
+      if (lane == 0) {
+        gmean[0] = (float)(m1 * (double)a.inv_count);
+        gmean[1] = (float)(m2 * (double)a.inv_count);
+      }
+    }
+    __syncthreads();
+    const float k1 = a.stats[2 * s + 1] * gmean[0], m2f = gmean[1];
+    float* po = a.dx + (size_t)s * slab + (size_t)member * SE + 4 * tid;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float4 o;
+      o.x = dp[v].x - k1 - xp[v].x * m2f;
+      o.y = dp[v].y - k1 - xp[v].y * m2f;
+      o.z = dp[v].z - k1 - xp[v].z * m2f;
+      o.w = dp[v].w - k1 - xp[v].w * m2f;
+      if (ADD) { o.x += ar[v].x; o.y += ar[v].y; o.z += ar[v].z; o.w += ar[v].w; }
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      *reinterpret_cast<float4*>(po + v * GNF_UNIT) = o;
+    }
+  };
+
+  int s = team;
+  if (s < a.NG) {
+    prefetch(s);
+    stage(s);
+    for (;;) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) { xp[v] = xq[v]; dp[v] = dq[v]; }
+      const int sn = s + a.nteams;
+      if (sn < a.NG) stage(sn);       // uniform
+      finish(s);
+      if (sn >= a.NG) break;
+      s = sn;
+    }
+  }
+  if (a.amax_part) {
+    amax = wave_max(amax);
+    if (lane == 0) a.amax_part[bid * NW + wave] = amax;
+  }
+}
+
 // after the fused kernel: dgamma / dbeta from the per-unit partials -- one 64-lane wave per channel, every lane a fixed
 // subset of the (image, unit) partials, butterfly at the end: deterministic, and N x HW/1024 (up to 1024) dependent
 // 8-byte loads per channel no longer sit in ONE thread (32 us per launch, 1.5 ms per step).  Block 0 also folds max |dx|.
@@ -548,11 +700,11 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
 }
 
 // plan of the fused backward for one shape: V float4 per thread, team size T; T = 0 when the shape is not eligible
-struct GnBwdPlan { int V, T, nteams, grid; };
+struct GnBwdPlan { int V, T, nteams, grid, pipe; };
 int g_gn_bwd_fused = -1;   // -1: take EOVAE_GN_BWD_FUSED (default on) at first use
 constexpr int GNF_MAX_GRID = 1024;   // 4 workgroups x 256 CUs
 GnBwdPlan gn_bwd_plan(int N, int C, int HW, int G) {
-  GnBwdPlan p = {0, 0, 0, 0};
+  GnBwdPlan p = {0, 0, 0, 0, 0};
   static int n_cu = 0;
   int& enabled = g_gn_bwd_fused;
   if (enabled < 0) {
@@ -566,19 +718,29 @@ GnBwdPlan gn_bwd_plan(int N, int C, int HW, int G) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
   }
   if (!enabled || n_cu <= 0 || HW % GNF_UNIT != 0) return p;
-  static const int vmax = getenv("EOVAE_GN_BWD_VMAX") ? atoi(getenv("EOVAE_GN_BWD_VMAX")) : 8;
+  // EOVAE_GN_BWD_PIPE=0: the single-stage kernel everywhere (A/B); default: the software-pipelined kernel (slices of
+  // at most 4 float4 pairs per thread: three register sets, three workgroups per CU), the single-stage kernel with
+  // slices of 8 only for slabs whose team would not fit the pipelined grid
+  static const int pipe_on = getenv("EOVAE_GN_BWD_PIPE") ? atoi(getenv("EOVAE_GN_BWD_PIPE")) : 1;
+  static const int vmax_env = getenv("EOVAE_GN_BWD_VMAX") ? atoi(getenv("EOVAE_GN_BWD_VMAX")) : 0;
   const size_t slab = (size_t)(C / G) * HW;
   const size_t q = slab / GNF_UNIT;
-  const int V = (q % 8 == 0 && vmax >= 8) ? 8 : (q % 4 == 0 && vmax >= 4) ? 4 : (q % 2 == 0 && vmax >= 2) ? 2 : 1;
-  int slots = gnf_wg_per_cu(V) * n_cu;        // resident workgroups
-  if (slots > GNF_MAX_GRID) slots = GNF_MAX_GRID;
-  const size_t T = q / V;
-  if (T > (size_t)slots) return p;
-  p.V = V;
-  p.T = (int)T;
   const int NG = N * G;
-  p.nteams = slots / p.T < NG ? slots / p.T : NG;
-  p.grid = p.nteams * p.T;
+  for (int pipe = pipe_on ? 1 : 0; pipe >= 0; --pipe) {
+    const int vmax = vmax_env ? vmax_env : (pipe ? 4 : 8);
+    if (pipe && vmax > 4) continue;
+    const int V = (q % 8 == 0 && vmax >= 8) ? 8 : (q % 4 == 0 && vmax >= 4) ? 4 : (q % 2 == 0 && vmax >= 2) ? 2 : 1;
+    int slots = gnf_wg_per_cu(V) * n_cu;        // resident workgroups
+    if (slots > GNF_MAX_GRID) slots = GNF_MAX_GRID;
+    const size_t T = q / V;
+    if (T > (size_t)slots) continue;
+    p.V = V;
+    p.T = (int)T;
+    p.nteams = slots / p.T < NG ? slots / p.T : NG;
+    p.grid = p.nteams * p.T;
+    p.pipe = pipe;
+    return p;
+  }
   return p;
 }
 // workspace of the fused backward: member granules | per-unit partials | per-wave maxima | time-out word
@@ -703,10 +865,10 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
   hipStream_t st = (hipStream_t)stream;
   const int cpg = C / G;
   GnBwdPlan plan = gn_bwd_plan(N, C, HW, G);
-  // measured (profiles/r03l_gn_bwd_ab.log): with 4 channels per group and no skip gradient to fold in, the two-pass
-  // kernels are 2 % faster (their second read of a 1 MiB slab is cheap, the hand-off is not); everywhere else the
-  // one-pass kernel wins by 1.00-1.36 x.  EOVAE_GN_BWD_FUSED=2 (or eovae_gn_bwd_fused(2)) forces it for every shape.
-  if (plan.T > 0 && g_gn_bwd_fused != 2 && !dx_add && cpg < 8) plan.T = 0;
+  // measured (profiles/r03l_gn_bwd_ab.log): the SINGLE-STAGE kernel loses 2 % to the two-pass kernels with 4 channels
+  // per group and no skip gradient to fold in; the software-pipelined kernel wins everywhere (1.18-1.43 x).
+  // EOVAE_GN_BWD_FUSED=2 (or eovae_gn_bwd_fused(2)) forces the one-pass kernel for every eligible shape.
+  if (plan.T > 0 && !plan.pipe && g_gn_bwd_fused != 2 && !dx_add && cpg < 8) plan.T = 0;
   if (plan.T > 0) {
     // token: unique per call AND per process -- the workspace may sit on device memory that an earlier (or a
     // concurrent) process filled with granules of the very same call sequence, so a plain call counter is not enough
@@ -751,7 +913,9 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
     a.nosync = nosync;
     void (*k)(GnBwdFArgs) = nullptr;
 #define EOVAE_GN_PICK(S, A)                                                                         \
-    k = plan.V == 8 ? gn_bwd_fused_kernel<S, A, 8> : plan.V == 4 ? gn_bwd_fused_kernel<S, A, 4>     \
+    k = plan.pipe ? (plan.V == 4 ? gn_bwd_fused_pipe_kernel<S, A, 4> : plan.V == 2 ? gn_bwd_fused_pipe_kernel<S, A, 2> \
+                                                                       : gn_bwd_fused_pipe_kernel<S, A, 1>)          \
+      : plan.V == 8 ? gn_bwd_fused_kernel<S, A, 8> : plan.V == 4 ? gn_bwd_fused_kernel<S, A, 4>     \
       : plan.V == 2 ? gn_bwd_fused_kernel<S, A, 2> : gn_bwd_fused_kernel<S, A, 1>
     if (silu && dx_add) EOVAE_GN_PICK(true, true);
     else if (silu) EOVAE_GN_PICK(true, false);
