@@ -332,6 +332,9 @@ __global__ __launch_bounds__(256) void amax_fold_kernel(const float* __restrict_
 // in `err`, and the finalize kernel poisons dgamma / dbeta with NaN.
 // The per-channel partials (for dgamma / dbeta) are plain stores, read by the finalize kernel after the launch.
 // The NEXT slab's loads are issued at the top of a round, before this slab's arithmetic.
+#ifndef EOVAE_GN_NOSYNC
+#define EOVAE_GN_NOSYNC 0   // 1: timing-only build that skips the team wait (WRONG results; tools/build_variant.sh)
+#endif
 constexpr int GNF_NT = 256;             // threads per workgroup
 constexpr int GNF_UNIT = GNF_NT * 4;
 // resident workgroups per CU by slice size (register budget: V = 8 needs ~220 VGPRs, V = 4 ~140, V <= 2 ~100)
@@ -348,7 +351,6 @@ struct GnBwdFArgs {
   unsigned long long token;
   int C, HW, cpg, G, T, nteams, NG;
   float inv_count;
-  int nosync;              // timing experiments only (EOVAE_GN_BWD_NOSYNC=1): skip the team wait -- WRONG results
 };
 
 // (taking the int by VALUE matters: __builtin_bit_cast applied to the element expression gv[1] itself read element 0)
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
       double m1 = 0, m2 = 0;
       const unsigned long long t0 = __builtin_readcyclecounter();   // s_memtime
       bool late = false;
-      for (int j = lane; j < (a.nosync ? 0 : a.T); j += 64) {
+      for (int j = lane; j < (EOVAE_GN_NOSYNC ? 0 : a.T); j += 64) {
         i32x4 gv;
         for (;;) {
           gv = granule_load(tg + j);
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       double m1 = 0, m2 = 0;
       const unsigned long long t0 = __builtin_readcyclecounter();
       bool late = false;
-      for (int j = lane; j < (a.nosync ? 0 : a.T); j += 64) {
+      for (int j = lane; j < (EOVAE_GN_NOSYNC ? 0 : a.T); j += 64) {
         i32x4 gv;
         for (;;) {
           gv = granule_load(tg + j);
@@ -909,8 +911,6 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
     a.token = z;
     a.C = C; a.HW = HW; a.cpg = cpg; a.G = G; a.T = plan.T; a.nteams = plan.nteams; a.NG = N * G;
     a.inv_count = (float)(1.0 / ((double)cpg * HW));
-    static const int nosync = getenv("EOVAE_GN_BWD_NOSYNC") ? atoi(getenv("EOVAE_GN_BWD_NOSYNC")) : 0;
-    a.nosync = nosync;
     void (*k)(GnBwdFArgs) = nullptr;
 #define EOVAE_GN_PICK(S, A)                                                                         \
     k = plan.pipe ? (plan.V == 4 ? gn_bwd_fused_pipe_kernel<S, A, 4> : plan.V == 2 ? gn_bwd_fused_pipe_kernel<S, A, 2> \
