@@ -286,3 +286,52 @@ def test_packed_records_fail_loudly_outside_the_convolution():
                lambda a: torch.cat([a, a]), lambda a: a.numpy()):
         with pytest.raises(EovaeError, match='operand records'):
             op(p)
+
+
+def test_groupnorm_backward_switch_and_plan_without_a_gpu():
+    """eovae_gn_bwd_fused: 0 / 1 / 2 set, anything else queries; no shape is eligible for the cooperative kernel on a
+    box without a GPU (the plan needs the CU count) and asking does not crash."""
+    from eo_vae_amd import lib as L
+    lib = L.load()
+    before = lib.eovae_gn_bwd_fused(-1)
+    try:
+        assert lib.eovae_gn_bwd_fused(0) == 0 and lib.eovae_gn_bwd_fused(-7) == 0
+        assert lib.eovae_gn_bwd_fused(2) == 2 and lib.eovae_gn_bwd_fused(99) == 2
+        assert lib.eovae_gn_bwd_fused(1) == 1
+        import torch
+        if not torch.cuda.is_available():
+            assert lib.eovae_gn_bwd_fused_eligible(16, 128, 256 * 256, 32) == 0
+        assert lib.eovae_gn_bwd_fused_eligible(0, 128, 4096, 32) == 0       # malformed shapes: not eligible, no error
+        assert lib.eovae_gn_bwd_fused_eligible(2, 100, 4096, 32) == 0
+        # the workspace covers the cooperative kernel's granules and partials when the shape could take it
+        assert lib.eovae_gn_workspace_bytes(2, 64, 4096, 32) >= 2 * 64 * 4 * (16 + 8)
+    finally:
+        lib.eovae_gn_bwd_fused(before if before in (0, 1, 2) else 1)
+
+
+def test_zero_pool_hands_out_disjoint_zeroed_slices():
+    """ops.zeros_small: slices of one pre-zeroed pool, never handed out twice, 256-byte aligned; big requests and a
+    used-up pool fall back to a fresh allocation."""
+    import torch
+    from eo_vae_amd import ops
+    dev = torch.device('cpu')
+    ops._ZERO_POOL.clear()
+    a = ops.zeros_small(5, torch.float32, dev)
+    b = ops.zeros_small(1024, torch.float32, dev)
+    c = ops.zeros_small(3, torch.float64, dev)
+    assert a.shape == (5,) and b.shape == (1024,) and c.dtype == torch.float64
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() != c.untyped_storage().data_ptr()
+    assert b.data_ptr() - a.data_ptr() == 64 * 4 and b.data_ptr() % 256 == a.data_ptr() % 256
+    a.fill_(1.0)
+    b.fill_(2.0)
+    d = ops.zeros_small(7, torch.float32, dev)
+    assert float(d.abs().sum()) == 0.0 and float(a.sum()) == 5.0 and float(b.sum()) == 2048.0
+    big = ops.zeros_small(ops._ZERO_POOL_ELEMS, torch.float32, dev)          # too large for the pool
+    assert big.untyped_storage().data_ptr() != a.untyped_storage().data_ptr() and float(big.abs().sum()) == 0.0
+    first = a.untyped_storage().data_ptr()
+    for _ in range(2 * ops._ZERO_POOL_ELEMS // (ops._ZERO_POOL_ELEMS // 8) + 2):   # exhaust the pool
+        e = ops.zeros_small(ops._ZERO_POOL_ELEMS // 8, torch.float32, dev)
+        assert float(e.abs().sum()) == 0.0
+        e.fill_(3.0)
+    assert e.untyped_storage().data_ptr() != first and float(a.sum()) == 5.0
+    ops._ZERO_POOL.clear()
