@@ -353,6 +353,13 @@ struct GnBwdFArgs {
   float inv_count;
 };
 
+// The token of THIS launch: the host's per-call value advanced by a device-side epoch that the finalize kernel bumps
+// at the end of every call.  A HIP graph replays a captured launch with its kernel arguments frozen -- without the
+// epoch every replay would carry the token of the capture, and the granules of the previous replay would validate.
+__device__ __forceinline__ unsigned long long gnf_token(const GnBwdFArgs& a) {
+  const unsigned long long epoch = *reinterpret_cast<const unsigned long long*>(a.ticket + 16);
+  return a.token + epoch * 0x9E3779B97F4A7C15ull;
+}
 // (taking the int by VALUE matters: __builtin_bit_cast applied to the element expression gv[1] itself read element 0)
 __device__ __forceinline__ float bits_f(int b) { return __builtin_bit_cast(float, b); }
 __device__ __forceinline__ void granule_store(i32x4* p, float s1, float s2, unsigned long long tok) {
@@ -383,6 +390,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
   if (tid == 0) ticket_s = atomicAdd(a.ticket, 1u) % gridDim.x;
   __syncthreads();
   const int bid = (int)ticket_s;
+  const unsigned long long token = gnf_token(a);
   const int team = bid / a.T, member = bid % a.T;
   const size_t slab = (size_t)a.cpg * a.HW;
   float4 xr[V], dr[V], xn[V], dn[V], ar[V];
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
       t1 = wave_sum_d(t1);
       t2 = wave_sum_d(t2);
       i32x4* tg = a.team + (size_t)s * a.T;
-      if (lane == 0) granule_store(tg + member, (float)t1, (float)t2, a.token);
+      if (lane == 0) granule_store(tg + member, (float)t1, (float)t2, token);
       // ---- wait for the team, fold its granules (fixed order: deterministic)
       double m1 = 0, m2 = 0;
       const unsigned long long t0 = __builtin_readcyclecounter();   // s_memtime
@@ -468,14 +476,14 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
         for (;;) {
           gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
-          if (tk == a.token) break;
+          if (tk == token) break;
           if (__builtin_readcyclecounter() - t0 > 4000000000ull) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         m1 += (double)bits_f(gv[0]);
         m2 += (double)bits_f(gv[1]);
       }
-      if (late) *a.err = a.token;
+      if (late) *a.err = token;
       m1 = wave_sum_d(m1);
       m2 = wave_sum_d(m2);
       if (lane == 0) {
@@ -519,6 +527,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
   if (tid == 0) ticket_s = atomicAdd(a.ticket, 1u) % gridDim.x;
   __syncthreads();
   const int bid = (int)ticket_s;
+  const unsigned long long token = gnf_token(a);
   const int team = bid / a.T, member = bid % a.T;
   const size_t slab = (size_t)a.cpg * a.HW;
   float4 xp[V], dp[V], xq[V], dq[V], xn[V], dn[V], ar[V];
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       }
       t1 = wave_sum_d(t1);
       t2 = wave_sum_d(t2);
-      if (lane == 0) granule_store(a.team + (size_t)s * a.T + member, (float)t1, (float)t2, a.token);
+      if (lane == 0) granule_store(a.team + (size_t)s * a.T + member, (float)t1, (float)t2, token);
     }
   };
   // wait for slab s' team, then write dx of slab s from P
@@ -605,14 +614,14 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
         for (;;) {
           gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
-          if (tk == a.token) break;
+          if (tk == token) break;
           if (__builtin_readcyclecounter() - t0 > 4000000000ull) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         m1 += (double)bits_f(gv[0]);
         m2 += (double)bits_f(gv[1]);
       }
-      if (late) *a.err = a.token;
+      if (late) *a.err = token;
       m1 = wave_sum_d(m1);
       m2 = wave_sum_d(m2);
       if (lane == 0) {
@@ -668,7 +677,16 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
                                                                     unsigned* __restrict__ ticket) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;   // (tickets are taken modulo the grid: a dirty counter is harmless)
+  // the launch's token (host value + device epoch, as gnf_token); the LAST block to get here resets the ticket counter
+  // and bumps the epoch for the next call -- the other blocks have read the epoch by then
+  unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 16);
+  token += *epoch * 0x9E3779B97F4A7C15ull;
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(ticket + 32, 1u) == gridDim.x - 1) {
+    ticket[32] = 0u;
+    ticket[0] = 0u;       // (tickets are taken modulo the grid: a dirty counter is harmless)
+    *epoch += 1;
+  }
   if (c < C) {
     const int G = C / cpg, g = c / cpg, cj = c % cpg, per = HW / GNF_UNIT;
     const size_t slab_units = (size_t)cpg * per;

@@ -124,3 +124,45 @@ def test_shapes_outside_the_plan_take_the_two_pass_kernels(fused_switch):
     assert lib.eovae_gn_bwd_fused_eligible(1, 32, 4096 * 2048, 1) == 0    # one slab would need more members than CUs
     lib.eovae_gn_bwd_fused(0)
     assert lib.eovae_gn_bwd_fused_eligible(2, 128, 256 * 256, 32) == 0
+
+
+def test_one_pass_backward_replays_inside_a_hip_graph(fused_switch):
+    """A captured launch is replayed with frozen kernel arguments: the hand-off token must still differ from replay to
+    replay (device-side epoch), or the granules of the previous replay would be taken for this one's."""
+    from eo_vae_amd import lib as L
+    lib = fused_switch
+    n, c, groups, h, w = 2, 128, 32, 64, 64                      # slab 16 units -> V 4, team 4
+    hw = h * w
+    x = (hashed((n, c, h, w), 41, 2.0) + 0.3).cuda()
+    g = (1.0 + hashed((c,), 42, 0.2)).cuda()
+    b = hashed((c,), 43, 0.2).cuda()
+    dy = torch.zeros(n, c, h, w, device='cuda')
+    stats = torch.empty(n * groups * 2, device='cuda')
+    y = torch.empty_like(x)
+    ws = torch.empty(lib.eovae_gn_workspace_bytes(n, c, hw, groups), dtype=torch.uint8, device='cuda')
+    L.check(lib.eovae_gn_silu_fwd(L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(y), L.ptr(stats), None, n, c, hw, groups, 1e-6, 1,
+                                  L.ptr(ws), L.stream()), 'fwd')
+    dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(b)
+
+    def call():
+        L.check(lib.eovae_gn_silu_bwd(L.ptr(x), L.ptr(dy), L.ptr(g), L.ptr(b), L.ptr(stats), None, L.ptr(dx), L.ptr(dg),
+                                      L.ptr(db), None, n, c, hw, groups, 1, L.ptr(ws), L.stream()), 'bwd')
+    lib.eovae_gn_bwd_fused(2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()                                                   # first use allocates the ticket word: not inside a capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for r in range(3):
+        dy.copy_(hashed((n, c, h, w), 50 + r, 1.0 + r).cuda())   # new gradients, same buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (dx.clone(), dg.clone(), db.clone())
+        lib.eovae_gn_bwd_fused(0)
+        call()
+        torch.cuda.synchronize()
+        lib.eovae_gn_bwd_fused(2)
+        assert rel_err(got[0], dx) < 2e-6 and rel_err(got[1], dg) < 2e-6 and rel_err(got[2], db) < 2e-6, r
