@@ -512,6 +512,27 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
   }
 }
 
+// streamed once: x, dy, the skip gradient and dx bypass the caches' retention (EOVAE_GN_NT=0 builds the plain form)
+#ifndef EOVAE_GN_NT
+#define EOVAE_GN_NT 1
+#endif
+__device__ __forceinline__ float4 gnf_ld(const float* p) {
+#if EOVAE_GN_NT
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void gnf_st(float* p, const float4& o) {
+#if EOVAE_GN_NT
+  f32x4 v;
+  v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = o;
+#endif
+}
 // Software-pipelined form of the kernel above (EOVAE_GN_BWD_PIPE=1): THREE register sets of V float4 pairs -- P (slab
 // s: partial sums published, waiting for its team), Q (slab s + 1: being summed) and N (slab s + 2: loads in flight).
 // The workgroup publishes slab s + 1 BEFORE it waits for slab s, so the hand-off latency of a slab is covered by the
@@ -540,8 +561,8 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       const float* pd = slice_ptr(a.dy, s);
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        xn[v] = *reinterpret_cast<const float4*>(px + v * GNF_UNIT);
-        dn[v] = *reinterpret_cast<const float4*>(pd + v * GNF_UNIT);
+        xn[v] = gnf_ld(px + v * GNF_UNIT);
+        dn[v] = gnf_ld(pd + v * GNF_UNIT);
       }
     }
   };
@@ -602,7 +623,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
     if (ADD) {
       const float* pa = slice_ptr(a.dx_add, s);
 #pragma unroll
-      for (int v = 0; v < V; ++v) ar[v] = *reinterpret_cast<const float4*>(pa + v * GNF_UNIT);
+      for (int v = 0; v < V; ++v) ar[v] = gnf_ld(pa + v * GNF_UNIT);
     }
     if (wave == 0) {
       const i32x4* tg = a.team + (size_t)s * a.T;
@@ -641,7 +662,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       o.w = dp[v].w - k1 - xp[v].w * m2f;
       if (ADD) { o.x += ar[v].x; o.y += ar[v].y; o.z += ar[v].z; o.w += ar[v].w; }
       amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-      *reinterpret_cast<float4*>(po + v * GNF_UNIT) = o;
+      gnf_st(po + v * GNF_UNIT, o);
     }
   };
 
