@@ -1666,6 +1666,11 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   }
   Cin = a.Cin; Cout = a.Cout; Hout = a.Hout; Wout = a.Wout;
   a.nchunk = Cin / 32; a.ncob = cdiv(Cout, 128);
+  // The epilogue's GroupNorm cells are folded behind the NEXT tile's first stage barrier and rewritten by that tile's
+  // epilogue: at least one more barrier must lie between the two, i.e. a tile needs two stages.  Plain layers have five
+  // per 32-channel chunk; the parity forms can have ONE per chunk, so they need two chunks (the model's have >= 16).
+  EOVAE_CHECK_ARG(!gn_sums || subpix == 0 || a.nchunk >= 2,
+                  "conv3x3_f16c8_fwd: gn_sums with a parity form needs at least 64 K channels (got %d)", Cin);
   a.tiles_x = cdiv(Wout, 32);
   hipStream_t st = (hipStream_t)stream;
   auto xcd_ok = [&](long long tiles) { return (a.ncob > 1 && tiles % 8 == 0) ? 1 : 0; };
