@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   int tile = blockIdx.x;
   if (tile >= a.ntiles) return;
   // Start stagger (experiment hook EOVAE_C8_W4_STAGGER, default off): eight block groups start
-  // group x stagger x 1024 cycles apart.  Measured: no gain at 3 / 6 / 10 (DESIGN.md s5.3).
+  // group x stagger x 1024 cycles apart.  Measured: no gain at 3 / 6 / 10 (DESIGN.md s5.0).
   if (a.stagger) {
     const int g = (blockIdx.x >> 3) & 7;
     for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
@@ -607,7 +607,7 @@ extern "C" int eovae_debug_w4_stamps(void* dst, size_t bytes) {
 // rows per wave: 4 = 16-row tiles, one block per CU (default).  2 = 8-row tiles, two skewed blocks per CU: an
 // EXPERIMENT (EOVAE_C8_W4_NI=2, record inputs only) that did not pay -- the CU's older block wins the issue arbitration,
 // finishes its eight tiles in 0.69 M cycles while the younger one needs 0.93 M, and the layer takes as long as with
-// one block per CU (tools/w4_stamps.py; DESIGN.md s5.3).  fp32 inputs always take 4 rows per wave: the 2-row fp32
+// one block per CU (tools/w4_stamps.py; DESIGN.md s5.0).  fp32 inputs always take 4 rows per wave: the 2-row fp32
 // variant spills 50 registers into the phase sequence and is not used.
 static int w4_rows_per_wave(const ConvCArgs& a, int n_cu) {
   const char* env = getenv("EOVAE_C8_W4_NI");

@@ -17,6 +17,11 @@
 //                    (First build: X through registers too = 80 staging registers; with 288 accumulators the compiler
 //                    spilled 260 registers INTO the tile loop, every reload behind an s_waitcnt vmcnt(0) that drained
 //                    the prefetch: 3.5 x SLOWER than the 8-wave kernel.)
+// STATUS: correct (tests/test_gpu_wgrad_w4.py) and PARKED -- 0.77-0.87 x the 8-wave kernel at the model's shapes, so it
+// only runs with EOVAE_C8_WGRAD_W4=1.  One wave per SIMD hides ~24 issue cycles per 32-cycle MFMA; a weight-gradient
+// tile (216 MFMAs = 4,608 cycles) needs ~3,600 of issue for its dY split, LDS-DMA instructions and their address math,
+// and fragment reads -- the 8-wave kernel has twice the issue slots for the same MFMA time.  A/B, timing-only
+// ablations (EOVAE_WG4_ABL) and SQ counters: profiles/r03k_wgrad_w4_ablation.log, profiles/r03i_pmc_sq.json, DESIGN.md s5.0.
 // Restrictions (else the 8-wave kernel runs): plain form (subpix 0, mode NORMAL), record input, Cout % 128 == 0,
 // Cin % 64 == 0, Wout % 32 == 0, Hout % 2 == 0.
 #include <stdlib.h>

@@ -316,30 +316,33 @@ __global__ __launch_bounds__(256) void amax_fold_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward, ONE pass over the activation (12 B per element instead of the 20 of reduce + apply):
-// a persistent grid of at most TWO 256-thread workgroups per CU.  A TEAM of T workgroups owns one (image, group) slab
-// at a time; each member loads its slice of x and dy ONCE into registers (V float4 of each per thread), publishes its
-// partial sums (s1 = sum dz, s2 = sum dz * xhat), waits until the whole team has published, folds the team's partials
-// into the group means m1, m2 and writes dx from the registers.  The slab is never re-read, so nothing depends on what
-// a cache still holds.  Two workgroups per CU: while one computes or waits for its team, the other one streams.
+// backward, ONE pass over the activation (12 B per element instead of the 20 of reduce + apply; 16 instead of 24 with
+// a skip gradient): a persistent grid of 256-thread workgroups, two to four per CU by slice size.  A TEAM of T
+// workgroups owns one (image, group) slab at a time; each member loads its slice of x and dy ONCE into registers
+// (V float4 of each per thread), publishes its partial sums (s1 = sum dz, s2 = sum dz * xhat), waits until the whole
+// team has published, folds the team's partials into the group means m1, m2 and writes dx from the registers.  The
+// slab is never re-read, so nothing depends on what a cache still holds.
 //
 // Hand-off between workgroups (MI355X_MICROARCH.md, cross-workgroup visibility): a member's contribution to the group
 // means travels as ONE 16-byte granule {sum s1 gamma, sum s2 gamma, 64-bit token} stored and polled with sc0 sc1 --
-// the granule validates itself, so no fence, no flag and no counter to reset; the token is unique per call and per
-// process (64 pseudo-random bits), stale granules of earlier calls or of other processes never match.  Every workgroup of the grid is resident (grid <= 2 x CUs;
-// two workgroups of <= 256 VGPRs and 0.3 KiB of LDS per CU fit by construction) and publishes before it waits, so the
-// wait ends; it is bounded all the same (4e9 shader clocks, about 2 s): on a time-out the workgroup records the token
-// in `err`, and the finalize kernel poisons dgamma / dbeta with NaN.
+// the granule validates itself, so no fence, no flag and no counter to reset.  The token is unique per call, per
+// process and per graph replay (gnf_token below): stale granules never match.
+// Progress: logical workgroup ids are tickets taken in order of ARRIVAL, so the workgroups that are resident always
+// hold the lowest ids, i.e. whole teams plus at most one partial team; a whole team needs nobody else, finishes and
+// frees its slots.  (grid <= workgroups-per-CU x CUs, so normally everything is resident anyway; the tickets cover a GPU
+// shared with another process or with RCCL's kernels.)  The wait is bounded all the same (4e9 shader clocks, ~2 s):
+// on a time-out the workgroup records the token in `err`, and the finalize kernel poisons dgamma / dbeta with NaN.
 // The per-channel partials (for dgamma / dbeta) are plain stores, read by the finalize kernel after the launch.
-// The NEXT slab's loads are issued at the top of a round, before this slab's arithmetic.
+// Two forms: gn_bwd_fused_kernel (one slab per workgroup in flight; A/B reference, and the form for slabs whose team
+// would not fit the other's grid) and gn_bwd_fused_pipe_kernel (software-pipelined over slabs; the default).
 #ifndef EOVAE_GN_NOSYNC
 #define EOVAE_GN_NOSYNC 0   // 1: timing-only build that skips the team wait (WRONG results; tools/build_variant.sh)
 #endif
 constexpr int GNF_NT = 256;             // threads per workgroup
-constexpr int GNF_UNIT = GNF_NT * 4;
-// resident workgroups per CU by slice size (register budget: V = 8 needs ~220 VGPRs, V = 4 ~140, V <= 2 ~100)
+constexpr int GNF_UNIT = GNF_NT * 4;    // elements one float4 per thread covers: the unit of the per-channel partials
+// resident workgroups per CU by slice size (register budget: V = 8 needs ~220 VGPRs, V = 4 ~160 in the pipelined form,
+// V <= 2 ~100)
 constexpr int gnf_wg_per_cu(int V) { return V >= 8 ? 2 : V == 4 ? 3 : 4; }
-//    // elements one float4 per thread covers: the unit of the per-channel partials
 struct GnBwdFArgs {
   const float *x, *dy, *gamma, *beta, *stats, *dx_add;
   float* dx;
