@@ -14,6 +14,6 @@ void eovae_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* eovae_last_error(void) { return g_err; }
-int eovae_abi_version(void) { return 7; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches
+int eovae_abi_version(void) { return 8; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

@@ -47,6 +47,9 @@ SIGNATURES = {
     'eovae_gn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eovae_gn_silu_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_gn_silu_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'eovae_conv3x3_thin_wgrad_workspace': (_sz, [_i, _i, _i, _i, _i]),
+    'eovae_conv3x3_thin_wgrad_eligible': (_i, [_i, _i, _i, _i, _i, _i]),
+    'eovae_conv3x3_thin_wgrad': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     'eovae_gn_bwd_fused': (_i, [_i]),
     'eovae_gn_bwd_fused_eligible': (_i, [_i, _i, _i, _i]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
@@ -86,7 +89,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 8  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

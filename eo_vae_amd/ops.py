@@ -258,6 +258,9 @@ def gn_sums_of(x, groups):
 # layer (the residual stream in front of a Downsample / Upsample layer, the latent in front of the decoder's conv_in):
 # one absmax pass per such tensor (7 per step, ~0.3 ms) buys the removal of the |x| < 65 504 assumption.
 RANGE_GUARD = os.environ.get('EOVAE_F16C8_RANGE_GUARD', '1') != '0'
+# fp32 weight-gradient kernel for the first / last layer with <= 4 channels on the thin side (csrc/conv_thin.hip); 0 = the
+# matrix-core kernels as for every other layer (A/B)
+THIN_WGRAD = os.environ.get('EOVAE_THIN_WGRAD', '1') != '0'
 
 
 def range_amax(x):
@@ -630,7 +633,18 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 L.check(lib.eovae_upsample2x_bwd(L.ptr(du), L.ptr(dx), n, cin, h, w, L.stream()),
                         'eovae_upsample2x_bwd')
-        if ctx.needs_input_grad[1] and subpix:
+        thin = (THIN_WGRAD and ks == 3 and m == MODE_NORMAL and CONV_PRECISION != 'f32' and ctx.needs_input_grad[1] and
+                lib.eovae_conv3x3_thin_wgrad_eligible(n, cin, h, w, cout, int(ctx.packed)) == 1)
+        if thin:
+            # the wavelength-conditioned first / last layer with <= 4 channels on its thin side: an HBM-bound fp32 pass
+            # (csrc/conv_thin.hip) instead of a 128-row matrix-core tile with 3 valid rows
+            dw = torch.empty_like(weight)
+            if want_db and cout > cin:
+                db = torch.empty(cout, dtype=torch.float32, device=x.device)
+            ws = workspace(lib.eovae_conv3x3_thin_wgrad_workspace(n, cin, h, w, cout), x.device)
+            L.check(lib.eovae_conv3x3_thin_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), n, cin, h, w, cout,
+                                                 int(ctx.packed), L.ptr(ws), L.stream()), 'eovae_conv3x3_thin_wgrad')
+        elif ctx.needs_input_grad[1] and subpix:
             if want_db and CONV_PRECISION == 'f16c8':
                 db = zeros_small(cout, torch.float32, x.device)
             dw = up_conv_subpix_wgrad(x, dy, weight, db, getattr(ctx, 'x_amax', None))

@@ -138,6 +138,19 @@ int eovae_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dwp, float*
 int eovae_conv2d_wgrad(const float* x, const float* dy, float* dwp, int N, int Cin, int Hin,
                        int Win, int Cout, int Hout, int Wout, int KS, int mode, void* stream);
 /* dwp[tap][Cout][Cin] -> dw[Cout][Cin][KS][KS] */
+/* ----------------------------------------------------------------------------------------
+ * Weight gradient of the wavelength-conditioned first / last 3x3 convolutions when the thin side has at most 4
+ * channels (csrc/conv_thin.hip; reference dynamic_conv.py:186-206 DynamicConv.forward, :231-246
+ * DynamicConv_decoder.forward -> F.conv2d): plain fp32 FMAs, one pass over the many-channel tensor, partial sums
+ * folded in a fixed order (deterministic).  dw[Cout][Cin][3][3] is WRITTEN (PyTorch layout, no unpack step);
+ * db[Cout] (nullable) is written only when Cout > Cin.  x may be operand records (xpacked = 1) when Cin > Cout.
+ * ws: eovae_conv3x3_thin_wgrad_workspace(...) bytes.  _eligible: 1 when the shape is taken (plain 3x3, stride 1,
+ * min(Cin, Cout) <= 4, the other side >= 32 and a multiple of 4 (8 for records), W <= 256). */
+size_t eovae_conv3x3_thin_wgrad_workspace(int N, int Cin, int H, int W, int Cout);
+int eovae_conv3x3_thin_wgrad_eligible(int N, int Cin, int H, int W, int Cout, int xpacked);
+int eovae_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int Cin, int H, int W,
+                             int Cout, int xpacked, void* ws, void* stream);
+
 int eovae_conv_unpack_wgrad(const float* dwp, float* dw, int Cout, int Cin, int KS, void* stream);
 /* db[C] = sum_{n,hw} dy[N][C][HW] */
 int eovae_bias_grad(const float* dy, float* db, int N, int C, int HW, void* stream);
