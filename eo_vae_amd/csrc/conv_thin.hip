@@ -232,3 +232,153 @@ int eovae_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw, float* 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward of the LAST layer (many -> at most 4 channels; reference dynamic_conv.py:231-246, F.conv2d(img_feat, weight,
+// bias, padding=1)):  y[n][co][p] = b[co] + sum_{ci, tap} w[co][ci][tap] * x[n][ci][p + tap]
+// On the 8-wave matrix-core kernel this layer is a 128-row tile with 3 valid rows (0.54 ms per step, 13 TFLOP/s); the
+// work is 7 GFLOP over one pass of x (537 MB): HBM-bound.  fp32 FMAs:
+//   workgroup = image x 16 output rows x 64 columns; per channel octet the halo tile (18 x 66 pixels) is decoded ONCE
+//   into LDS as fp32 [row][column][8 channels] (records: f16 + e5m2(lo') * 2^-12; fp32 input: eight planes), then a
+//   thread (column c, row quartet q) takes its six halo rows x three columns x 8 channels into registers (36 16-byte
+//   LDS reads) and runs 8 x 9 x CO x 4 FMAs whose weights are wave-uniform (scalar loads).  y accumulates in registers
+//   across the octets and is stored once.
+namespace {
+
+constexpr int TF_ROWS = 16, TF_COLS = 64;
+
+struct ThinFwdArgs {
+  const float* x;      // [N][Cin][H][W] fp32, or operand records
+  const float* w;      // [Cout][Cin][3][3]
+  const float* bias;   // [Cout] or null
+  float* y;            // [N][Cout][H][W]
+  int N, Cin, Cout, H, W, tiles_x, tiles_y;
+};
+
+template <bool XREC, int CO>
+__global__ __launch_bounds__(256) void thin_fwd_kernel(ThinFwdArgs a) {
+  __shared__ float4 tile[(TF_ROWS + 2) * (TF_COLS + 2) * 2];   // [row][column][2 x float4 = 8 channels]
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int y0 = ty * TF_ROWS, x0 = tx * TF_COLS;
+  const size_t plane = (size_t)a.H * a.W;
+  const int col = tid & 63, rq = tid >> 6;           // column of the tile, row quartet (one wave each)
+  float acc[4][CO];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[r][co] = 0.f;
+
+  for (int oct = 0; oct < a.Cin / 8; ++oct) {
+    __syncthreads();   // the previous octet's tile has been read
+    for (int i = tid; i < (TF_ROWS + 2) * (TF_COLS + 2); i += 256) {
+      const int rr = i / (TF_COLS + 2), cc = i - rr * (TF_COLS + 2);
+      const int yy = y0 - 1 + rr, xx = x0 - 1 + cc;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+        const size_t pix = (size_t)yy * a.W + xx;
+        if (XREC) {
+          const char* rec = reinterpret_cast<const char*>(a.x) + (((size_t)n * (a.Cin / 8) + oct) * plane + pix) * 32;
+          const uint4 h = *reinterpret_cast<const uint4*>(rec);
+          const uint2 lo = *reinterpret_cast<const uint2*>(rec + 16);
+          auto dec = [](unsigned hw, unsigned lb) __attribute__((always_inline)) {
+            return (float)__builtin_bit_cast(_Float16, (unsigned short)hw) + e5m2_f(lb) * 0x1p-12f;
+          };
+          v0.x = dec(h.x & 0xffffu, lo.x & 0xffu);         v0.y = dec(h.x >> 16, (lo.x >> 8) & 0xffu);
+          v0.z = dec(h.y & 0xffffu, (lo.x >> 16) & 0xffu); v0.w = dec(h.y >> 16, lo.x >> 24);
+          v1.x = dec(h.z & 0xffffu, lo.y & 0xffu);         v1.y = dec(h.z >> 16, (lo.y >> 8) & 0xffu);
+          v1.z = dec(h.w & 0xffffu, (lo.y >> 16) & 0xffu); v1.w = dec(h.w >> 16, lo.y >> 24);
+        } else {
+          const float* p = a.x + ((size_t)n * a.Cin + 8 * oct) * plane + pix;
+          v0.x = p[0]; v0.y = p[plane]; v0.z = p[2 * plane]; v0.w = p[3 * plane];
+          v1.x = p[4 * plane]; v1.y = p[5 * plane]; v1.z = p[6 * plane]; v1.w = p[7 * plane];
+        }
+      }
+      tile[2 * i] = v0;
+      tile[2 * i + 1] = v1;
+    }
+    __syncthreads();
+    // the quartet's six halo rows x three columns x 8 channels in registers: every weight (wave-uniform: nine scalar
+    // registers per (output channel, input channel)) then feeds FOUR FMAs, one per output row.  (First form: a sliding
+    // 3-row window and all 216 weights of the octet live across the row loop = 225 spilled scalar registers, a
+    // v_readlane per FMA: 340 us per launch.)
+    float win[6][3][8];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int e = 2 * ((4 * rq + rr) * (TF_COLS + 2) + col + k);
+        const float4 u0 = tile[e], u1 = tile[e + 1];
+        win[rr][k][0] = u0.x; win[rr][k][1] = u0.y; win[rr][k][2] = u0.z; win[rr][k][3] = u0.w;
+        win[rr][k][4] = u1.x; win[rr][k][5] = u1.y; win[rr][k][6] = u1.z; win[rr][k][7] = u1.w;
+      }
+    const float* wo = a.w + (size_t)oct * 8 * 9;   // w[co][8 oct + j][tap] = wo[(co * Cin + j) * 9 + tap]
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // nine wave-uniform weights: scalar loads.  (Through LDS broadcast reads instead, the compiler hoisted all 216
+        // of the octet into vector registers: 256 VGPRs, one wave per SIMD, 476 us.)
+        const float* wp = wo + ((size_t)co * a.Cin + j) * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float wv = wp[ky * 3 + kx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r][co] = __builtin_fmaf(wv, win[r + ky][kx][j], acc[r][co]);
+          }
+      }
+  }
+  const int xo = x0 + col;
+  if (xo < a.W) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yo = y0 + 4 * rq + r;
+      if (yo < a.H) {
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+          a.y[((size_t)n * a.Cout + co) * plane + (size_t)yo * a.W + xo] = acc[r][co] + (a.bias ? a.bias[co] : 0.f);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when eovae_conv3x3_thin_fwd takes the shape: plain 3x3, stride 1, at most 4 output channels, Cin a multiple of 8
+int eovae_conv3x3_thin_fwd_eligible(int N, int Cin, int H, int W, int Cout) {
+  return (N > 0 && H > 0 && W > 0 && Cout >= 1 && Cout <= 4 && Cin >= 32 && Cin % 8 == 0) ? 1 : 0;
+}
+
+// y[N][Cout][H][W] = conv3x3(x, w[Cout][Cin][3][3]) + bias (nullable); x fp32 or operand records (xpacked = 1)
+int eovae_conv3x3_thin_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+                           int Cout, int xpacked, void* stream) {
+  EOVAE_CHECK_ARG(x && w && y, "conv3x3_thin_fwd: null pointer");
+  EOVAE_CHECK_ARG(eovae_conv3x3_thin_fwd_eligible(N, Cin, H, W, Cout),
+                  "conv3x3_thin_fwd: shape not supported (N %d Cin %d H %d W %d Cout %d)", N, Cin, H, W, Cout);
+  hipStream_t st = (hipStream_t)stream;
+  ThinFwdArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.tiles_x = cdiv(W, TF_COLS); a.tiles_y = cdiv(H, TF_ROWS);
+  const int blocks = N * a.tiles_x * a.tiles_y;
+#define EOVAE_THIN_FWD(REC)                                                                                   \
+  switch (Cout) {                                                                                              \
+    case 1: hipLaunchKernelGGL((thin_fwd_kernel<REC, 1>), dim3(blocks), dim3(256), 0, st, a); break;            \
+    case 2: hipLaunchKernelGGL((thin_fwd_kernel<REC, 2>), dim3(blocks), dim3(256), 0, st, a); break;            \
+    case 3: hipLaunchKernelGGL((thin_fwd_kernel<REC, 3>), dim3(blocks), dim3(256), 0, st, a); break;            \
+    default: hipLaunchKernelGGL((thin_fwd_kernel<REC, 4>), dim3(blocks), dim3(256), 0, st, a); break;           \
+  }
+  if (xpacked) { EOVAE_THIN_FWD(true) } else { EOVAE_THIN_FWD(false) }
+#undef EOVAE_THIN_FWD
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_thin_fwd");
+  return EOVAE_OK;
+}
+
+}  // extern "C"

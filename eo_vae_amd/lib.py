@@ -50,6 +50,8 @@ SIGNATURES = {
     'eovae_conv3x3_thin_wgrad_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'eovae_conv3x3_thin_wgrad_eligible': (_i, [_i, _i, _i, _i, _i, _i]),
     'eovae_conv3x3_thin_wgrad': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    'eovae_conv3x3_thin_fwd_eligible': (_i, [_i, _i, _i, _i, _i]),
+    'eovae_conv3x3_thin_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_gn_bwd_fused': (_i, [_i]),
     'eovae_gn_bwd_fused_eligible': (_i, [_i, _i, _i, _i]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),

@@ -564,6 +564,14 @@ class Conv2dFn(torch.autograd.Function):
             y = up_conv_subpix(x, weight, bias_c)
         elif ks == 3 and m == MODE_DOWN and res is None and _down_ok(x, weight):
             y = down_conv_s2d(x, weight, bias_c)
+        elif (THIN_WGRAD and ks == 3 and m == MODE_NORMAL and res is None and CONV_PRECISION != 'f32' and
+              L.load().eovae_conv3x3_thin_fwd_eligible(x.shape[0], cin, x.shape[2], x.shape[3], cout) == 1):
+            # the wavelength-conditioned LAST layer (<= 4 output channels): an HBM-bound fp32 pass (csrc/conv_thin.hip)
+            # instead of a 128-row matrix-core tile with 3 valid rows
+            y = torch.empty(x.shape[0], cout, x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+            L.check(L.load().eovae_conv3x3_thin_fwd(L.ptr(x), L.ptr(weight), L.ptr(bias_c), L.ptr(y), x.shape[0], cin,
+                                                    x.shape[2], x.shape[3], cout, int(packed), L.stream()),
+                    'eovae_conv3x3_thin_fwd')
         elif ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':
             wp = None
             ctx.wp_bwd = None

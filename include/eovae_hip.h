@@ -150,6 +150,11 @@ size_t eovae_conv3x3_thin_wgrad_workspace(int N, int Cin, int H, int W, int Cout
 int eovae_conv3x3_thin_wgrad_eligible(int N, int Cin, int H, int W, int Cout, int xpacked);
 int eovae_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int Cin, int H, int W,
                              int Cout, int xpacked, void* ws, void* stream);
+/* Forward of the last layer (at most 4 output channels, Cin a multiple of 8 and >= 32; x fp32 or operand records):
+ * y = conv3x3(x, w[Cout][Cin][3][3], padding 1) + bias (nullable), fp32 FMAs, one pass over x. */
+int eovae_conv3x3_thin_fwd_eligible(int N, int Cin, int H, int W, int Cout);
+int eovae_conv3x3_thin_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+                           int Cout, int xpacked, void* stream);
 
 int eovae_conv_unpack_wgrad(const float* dwp, float* dw, int Cout, int Cin, int KS, void* stream);
 /* db[C] = sum_{n,hw} dy[N][C][HW] */

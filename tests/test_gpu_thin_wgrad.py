@@ -100,3 +100,44 @@ def test_dynamic_conv_shapes_take_the_thin_kernel_through_autograd(mode):
             assert rel(bg.grad, br.grad) < 1e-5
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 3, 64, 64), (1, 64, 4, 33, 100), (3, 32, 1, 17, 70), (2, 128, 2, 256, 256)])
+def test_thin_forward_against_float64(n, cin, cout, h, w):
+    from eo_vae_amd import lib as L
+    lib = L.load()
+    assert lib.eovae_conv3x3_thin_fwd_eligible(n, cin, h, w, cout) == 1
+    x = hashed((n, cin, h, w), 91, 1.0)
+    wt = hashed((cout, cin, 3, 3), 92, 1.0 / (cin * 9) ** 0.5)
+    b = hashed((cout,), 93, 0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    xg, wg, bg = x.cuda(), wt.cuda(), b.cuda()
+    y = torch.full((n, cout, h, w), float('nan'), device='cuda')
+    L.check(lib.eovae_conv3x3_thin_fwd(L.ptr(xg), L.ptr(wg), L.ptr(bg), L.ptr(y), n, cin, h, w, cout, 0, L.stream()), 'thin fwd')
+    torch.cuda.synchronize()
+    assert rel(y, want) < 2e-6
+    L.check(lib.eovae_conv3x3_thin_fwd(L.ptr(xg), L.ptr(wg), None, L.ptr(y), n, cin, h, w, cout, 0, L.stream()), 'thin fwd')
+    torch.cuda.synchronize()
+    assert rel(y, want - b.double().view(1, -1, 1, 1)) < 2e-6
+
+
+def test_thin_forward_reads_operand_records():
+    from eo_vae_amd import lib as L, ops
+    lib = L.load()
+    n, cin, cout, h, w = 2, 128, 3, 48, 80
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    try:
+        x0 = hashed((n, cin, h, w), 95, 2.0).cuda()
+        g = (1.0 + hashed((cin,), 96, 0.2)).cuda()
+        b0 = hashed((cin,), 97, 0.2).cuda()
+        rec = ops.group_norm_silu(x0, g, b0, 32, 1e-6, True, True).detach()
+        yv = ops.group_norm_silu(x0, g, b0, 32, 1e-6, True, False).detach()
+        wt = hashed((cout, cin, 3, 3), 98, 1.0 / (cin * 9) ** 0.5).cuda()
+        b = hashed((cout,), 99, 0.1).cuda()
+        want = F.conv2d(yv.double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1)
+        got = ops.conv2d(rec, wt, b)                      # the autograd function routes the record input to the thin kernel
+        torch.cuda.synchronize()
+        assert not ops.is_packed(got)
+        assert rel(got, want) < 2e-5                      # records carry ~2^-14 per element
+    finally:
+        ops.CONV_PRECISION = old
