@@ -1385,6 +1385,20 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
       const int tap = SUBPIX == 1 ? (py + (t >> 1)) * 3 + px + (t & 1)
                                   : (SUBPIX == 2 ? (1 + (t >> 1)) * 3 + 1 + (t & 1) : t);
       if (SUBPIX == 2 && (((t >> 1) && py) || ((t & 1) && px))) continue;
+      if (SUBPIX == 0 && a.part) {
+        // plain stores into this block's own partial tile [tap][128 co][64 ci] (folded in a fixed order afterwards):
+        // the float atomics of the 256 blocks were 75 MB per launch at the chip's 1.3 TB/s atomic rate, all at the
+        // end of the launch -- 58 us of every weight-gradient launch, 30 % of the 512-channel 32^2 ones
+        float* pt = a.part + (((size_t)slab * a.split + ysub) * 9 + tap) * (128 * 64) + cih * 32 + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int col = (ct + c) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            pt[col * 64] = acc[tl][c][q] * dyinv;
+          }
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -1394,6 +1408,27 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
         }
     }
   }
+}
+
+// dw[Cout][Cin][3][3] (PyTorch layout) = sum over the `split` partial tiles of each (co-block, ci-block) slab, in a
+// fixed order: deterministic, and the unpack step is gone.  One thread per (co, ci, tap).
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+                                                         int Cin, int ncib, int split) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)9 * Cout * Cin) return;
+  const int ci = (int)(i % Cin);
+  const int co = (int)((i / Cin) % Cout);
+  const int tap = (int)(i / ((size_t)Cin * Cout));
+  const int slab = (co >> 7) * ncib + (ci >> 6);
+  const float* p = part + (((size_t)slab * split) * 9 + tap) * (128 * 64) + (co & 127) * 64 + (ci & 63);
+  float s0 = 0.f, s1 = 0.f;
+  int y = 0;
+  for (; y + 1 < split; y += 2) {
+    s0 += p[(size_t)y * 9 * 128 * 64];
+    s1 += p[(size_t)(y + 1) * 9 * 128 * 64];
+  }
+  if (y < split) s0 += p[(size_t)y * 9 * 128 * 64];
+  dw[((size_t)co * Cin + ci) * 9 + tap] = s0 + s1;
 }
 
 
@@ -1719,17 +1754,20 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
 // dwp[9][Cout][Cin] += dY (x) Xv with f16c8 operands; arguments as eovae_conv3x3_bf16_wgrad plus dyamax
 // (device pointer to the float bits of max|dy|, eovae_absmax_bits / eovae_gn_silu_bwd; NULL = unscaled dy) and xamax
 // (the same for an fp32 x that is not a GroupNorm output; NULL = x used unscaled, i.e. assumed inside f16's range)
-int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db, const unsigned* dyamax,
-                              const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
-                              int mode, int subpix, int xpacked, void* stream) {
-  EOVAE_CHECK_ARG(x && dy && dwp, "conv3x3_f16c8_wgrad: null pointer");
+}  // extern "C"
+
+// dwp (pre-zeroed, atomics; every form) OR part + dw (plain layers: partial tiles, folded into dw[Cout][Cin][3][3])
+static int c8_wgrad_impl(const float* x, const float* dy, float* dwp, float* part, float* dw, float* db,
+                         const unsigned* dyamax, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
+                         int Hout, int Wout, int mode, int subpix, int xpacked, void* stream) {
+  EOVAE_CHECK_ARG(x && dy && (dwp || (part && dw)), "conv3x3_f16c8_wgrad: null pointer");
   EOVAE_CHECK_ARG(subpix >= 0 && subpix <= 2, "conv3x3_f16c8_wgrad: subpix %d", subpix);
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_f16c8_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && mode == MODE_NORMAL && Cin % 64 == 0),
                   "conv3x3_f16c8_wgrad: packed x needs a plain layer with Cin %% 64 == 0");
   WgCArgs a;
   EOVAE_CHECK_ARG(!(xpacked && xamax), "conv3x3_f16c8_wgrad: operand records carry no scale (xamax must be NULL)");
-  a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax; a.xamax = xamax;
+  a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax; a.xamax = xamax; a.part = part;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout;
   a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1;
   if (subpix == 1) {
@@ -1756,7 +1794,7 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
   hipStream_t st = (hipStream_t)stream;
   a.xpacked = xpacked;
   // one-wave-per-SIMD kernel (conv_f16c8_wgrad_w4.hip) for plain layers made of full tiles
-  if (eovae_c8_wgrad_w4_eligible(a)) {
+  if (!part && eovae_c8_wgrad_w4_eligible(a)) {
     eovae_c8_wgrad_w4_launch(a, st);
     EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad (w4)");
     return EOVAE_OK;
@@ -1765,8 +1803,43 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
   else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2, false>), grid, dim3(512), 0, st, a);
   else if (xpacked) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, true>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, false>), grid, dim3(512), 0, st, a);
+  if (part) {
+    const size_t total = (size_t)9 * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, Cout, Cin, a.ncib,
+                       split);
+  }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad");
   return EOVAE_OK;
+}
+
+extern "C" {
+
+int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db, const unsigned* dyamax,
+                              const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                              int mode, int subpix, int xpacked, void* stream) {
+  return c8_wgrad_impl(x, dy, dwp, nullptr, nullptr, db, dyamax, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, mode, subpix,
+                       xpacked, stream);
+}
+
+// bytes of scratch eovae_conv3x3_f16c8_wgrad_dw needs: one [9][128][64] fp32 tile per block of the launch
+size_t eovae_conv3x3_f16c8_wgrad_dw_workspace(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  const int nslab = cdiv(Cin, 64) * cdiv(Cout, 128);
+  int split = EOVAE_WGRAD_BLOCKS / nslab;
+  if (split < 1) split = 1;
+  return (size_t)nslab * split * 9 * 128 * 64 * sizeof(float);
+}
+
+// Weight gradient of a PLAIN 3x3 layer (mode 0, no sub-pixel form) straight into dw[Cout][Cin][3][3] (PyTorch layout,
+// written, not accumulated): the blocks store partial tiles into ws, a second kernel folds them in a fixed order --
+// no pre-zeroed accumulator, no float atomics (deterministic), no unpack step.  Other arguments as
+// eovae_conv3x3_f16c8_wgrad; db (nullable) is still accumulated atomically into a pre-zeroed [Cout].
+int eovae_conv3x3_f16c8_wgrad_dw(const float* x, const float* dy, float* dw, float* db, const unsigned* dyamax,
+                                 const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                 int xpacked, void* ws, void* stream) {
+  EOVAE_CHECK_ARG(dw && ws, "conv3x3_f16c8_wgrad_dw: null pointer");
+  return c8_wgrad_impl(x, dy, nullptr, (float*)ws, dw, db, dyamax, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, MODE_NORMAL, 0,
+                       xpacked, stream);
 }
 
 }  // extern "C"

@@ -38,6 +38,7 @@ struct WgCArgs {
   int subpix, creal, cpb;   // as WgBArgs (conv_bf16x3.hip)
   int ncob_, split, xcd_remap;
   int xpacked;              // x = f16c8 operand records (GroupNorm-apply)
+  float* part;              // plain layers: per-block partial sums [slab][split][9][128][64] instead of atomics into dwp (or null)
 };
 
 namespace {

@@ -261,6 +261,9 @@ RANGE_GUARD = os.environ.get('EOVAE_F16C8_RANGE_GUARD', '1') != '0'
 # fp32 weight-gradient kernel for the first / last layer with <= 4 channels on the thin side (csrc/conv_thin.hip); 0 = the
 # matrix-core kernels as for every other layer (A/B)
 THIN_WGRAD = os.environ.get('EOVAE_THIN_WGRAD', '1') != '0'
+# plain f16c8 weight gradients through per-block partial tiles + a fold (deterministic, no atomics); 0 = atomics into a
+# zero-filled accumulator + unpack (A/B)
+WGRAD_DIRECT = os.environ.get('EOVAE_WGRAD_DIRECT', '1') != '0'
 
 
 def range_amax(x):
@@ -310,7 +313,7 @@ def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode
                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
 
 
-def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False, xamax=None):
+def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False, xamax=None, dw=None):
     """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16.
     xamax: absmax bits of an fp32 x that is not a GroupNorm output (range_amax), or None."""
     lib = L.load()
@@ -323,7 +326,14 @@ def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, p
         # (subpix 2 = the stride-2 layer: its output grid is the low-res one)
         ev0, ev1 = WGRAD3X3_TIMER.bracket(2.0 * n * ho * wo * cout * cin * 9, 4.0 * (x.numel() + dy.numel()))
         ev0.record()
-    if CONV_PRECISION == 'f16c8':
+    if CONV_PRECISION == 'f16c8' and dw is not None:
+        # plain layer: partial tiles + a fold in a fixed order straight into dw (no zero-filled accumulator, no float
+        # atomics, no unpack launch)
+        ws = workspace(lib.eovae_conv3x3_f16c8_wgrad_dw_workspace(cin, cout), x.device)
+        L.check(lib.eovae_conv3x3_f16c8_wgrad_dw(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(amax), L.ptr(xamax), n,
+                                                 cin, h, w, cout, ho, wo, int(packed), L.ptr(ws), L.stream()),
+                'eovae_conv3x3_f16c8_wgrad_dw')
+    elif CONV_PRECISION == 'f16c8':
         L.check(lib.eovae_conv3x3_f16c8_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwp), L.ptr(db), L.ptr(amax), L.ptr(xamax), n,
                                               cin, h, w, cout, ho, wo, mode, subpix, int(packed), L.stream()),
                 'eovae_conv3x3_f16c8_wgrad')
@@ -662,6 +672,13 @@ class Conv2dFn(torch.autograd.Function):
             dw = down_conv_s2d_wgrad(x, dy, weight, db, getattr(ctx, 'x_amax', None))
         elif ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
             dw = conv1x1_lowp_wgrad(x, dy)
+        elif (ctx.needs_input_grad[1] and WGRAD_DIRECT and ks == 3 and m == MODE_NORMAL and CONV_PRECISION == 'f16c8'
+              and cin % 32 == 0):
+            dw = torch.empty_like(weight)
+            if want_db:
+                db = zeros_small(cout, torch.float32, x.device)
+            _launch_wgrad3x3(x, dy, None, db, n, cin, h, w, cout, dy.shape[2], dy.shape[3], m, 0, packed=ctx.packed,
+                             xamax=getattr(ctx, 'x_amax', None), dw=dw)
         elif ctx.needs_input_grad[1]:
             dwp = torch.zeros(ks * ks * cout * cin, dtype=torch.float32, device=x.device)
             if ks == 3 and m != MODE_DOWN and CONV_PRECISION != 'f32':

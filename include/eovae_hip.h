@@ -104,6 +104,14 @@ int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Ho
 int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float* db,
                               const unsigned* dyamax, const unsigned* xamax, int N, int Cin, int Hin, int Win,
                               int Cout, int Hout, int Wout, int mode, int subpix, int xpacked, void* stream);
+/* The same weight gradient for a PLAIN 3x3 layer (mode 0, subpix 0) written straight into dw[Cout][Cin][3][3] (PyTorch
+ * layout): the launch's blocks store partial tiles into ws (eovae_conv3x3_f16c8_wgrad_dw_workspace bytes), a second
+ * kernel folds them in a fixed order.  No pre-zeroed accumulator, no float atomics (bit-reproducible), no unpack
+ * step.  db (nullable, pre-zeroed [Cout]) is accumulated as before. */
+size_t eovae_conv3x3_f16c8_wgrad_dw_workspace(int Cin, int Cout);
+int eovae_conv3x3_f16c8_wgrad_dw(const float* x, const float* dy, float* dw, float* db, const unsigned* dyamax,
+                                 const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                 int xpacked, void* ws, void* stream);
 /* xamax (nullable, fp32 x only): float bits of max|x| for activations that are not GroupNorm outputs (the residual
  * stream in front of Downsample / Upsample layers, layers.py:33-37, 47-50): x is pre-scaled by an exact power of two
  * like dy, so the f16c8 operands make no assumption about its range.  The forward entry takes the same pointer as

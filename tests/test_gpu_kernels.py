@@ -294,3 +294,36 @@ def test_packed_records_survive_detach_and_clone():
         torch.cuda.synchronize()
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,packed', [(2, 64, 128, 32, 32, False), (3, 128, 192, 24, 40, True), (1, 512, 64, 16, 32, True)])
+def test_plain_weight_gradient_is_bit_reproducible(n, cin, cout, h, w, packed):
+    """Round 3: the plain f16c8 weight gradient goes through per-block partial tiles and a fold in a fixed order (no
+    float atomics): two runs give identical bits, and the result equals the atomic path's up to summation order."""
+    from eo_vae_amd import ops
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    try:
+        x = hashed((n, cin, h, w), 301, 1.0).cuda()
+        wt = hashed((cout, cin, 3, 3), 302, 1.0 / (cin * 9) ** 0.5).cuda()
+        b = hashed((cout,), 303, 0.1).cuda()
+        gy = hashed((n, cout, h, w), 304, 1e-3).cuda()
+        g = (1.0 + hashed((cin,), 305, 0.2)).cuda()
+        be = hashed((cin,), 306, 0.2).cuda()
+
+        def run(direct):
+            keep, ops.WGRAD_DIRECT = ops.WGRAD_DIRECT, direct
+            try:
+                wg, bg = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                inp = ops.group_norm_silu(x, g, be, 32, 1e-6, True, True) if packed else x
+                ops.conv2d(inp, wg, bg).backward(gy)
+                torch.cuda.synchronize()
+                return wg.grad.clone(), bg.grad.clone()
+            finally:
+                ops.WGRAD_DIRECT = keep
+        d1, b1 = run(True)
+        d2, _ = run(True)
+        a1, ba = run(False)
+        assert torch.equal(d1, d2)
+        assert rel_err(d1, a1) < 2e-6 and rel_err(b1, ba) < 2e-6
+    finally:
+        ops.CONV_PRECISION = old

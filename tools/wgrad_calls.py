@@ -22,10 +22,10 @@ calls = []
 orig = ops._launch_wgrad3x3
 
 
-def timed(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False, xamax=None):
+def timed(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False, xamax=None, dw=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    orig(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=packed, xamax=xamax)
+    orig(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=packed, xamax=xamax, dw=dw)
     e1.record()
     calls.append((e0, e1, cin, cout, h, w, ho, wo, subpix, packed))
 
