@@ -361,6 +361,21 @@ class EOFluxVAE(LightningModule):
             return optimizer.clip_grad_norm(self.clip_grad)
         return torch.nn.utils.clip_grad_norm_(optimizer.param_groups[0]['params'], self.clip_grad)
 
+    def _prepack_weights(self):
+        """f16c8 mode, training: pack the plain 3x3 weights of encoder and decoder once, up front (two launches instead
+        of ~180).  Rebuilt whenever a weight's storage has moved (optimiser flattening, .to(), a loaded checkpoint)."""
+        if not (ops.PREPACK and ops.CONV_PRECISION == 'f16c8' and torch.is_grad_enabled()):
+            return
+        pp = getattr(self, '_weight_prepack', None)
+        if pp is None or pp.stale():
+            from .layers import Conv2d
+            ws = [m.weight for m in list(self.encoder.modules()) + list(self.decoder.modules())
+                  if isinstance(m, Conv2d) and m.mode == 'normal' and m.weight.requires_grad]
+            pp = ops.WeightPrepack(ws) if ws and ws[0].is_cuda else None
+            self._weight_prepack = pp
+        if pp is not None:
+            pp.run()
+
     def training_step(self, batch, batch_idx, noise: torch.Tensor | None = None):
         opts = self.optimizers()
         opt_gen = opts[0] if isinstance(opts, (list, tuple)) else opts
@@ -369,26 +384,30 @@ class EOFluxVAE(LightningModule):
 
         images, wvs = batch[self.image_key], batch['wvs']
         target = images
-        scale_bins = [0.375, 0.5, 0.75]
-        if random.random() < self.p_prior:  # EQ-VAE latent equivariance (:605-619)
-            angle = random.choice([1, 2, 3])
-            scale = ((random.choice(scale_bins), random.choice(scale_bins)) if self.anisotropic
-                     else random.choice(scale_bins))
-            recon, posterior = self.forward(images, wvs, scale=scale, angle=angle, noise=noise)
-            target = ops.area_rot(images, recon.shape[-2:], angle)  # area resize + rot90, one kernel
-        elif random.random() < self.p_prior_s:  # prior preservation (:621-627)
-            recon, posterior = self.forward(images, wvs, scale=random.choice(scale_bins), noise=noise)
-            target = ops.area_rot(images, recon.shape[-2:], None)
-        else:
-            recon, posterior = self.forward(images, wvs, noise=noise)
+        self._prepack_weights()     # every plain 3x3 layer's f16c8 packs from two launches (ops.WeightPrepack)
+        try:
+            scale_bins = [0.375, 0.5, 0.75]
+            if random.random() < self.p_prior:  # EQ-VAE latent equivariance (:605-619)
+                angle = random.choice([1, 2, 3])
+                scale = ((random.choice(scale_bins), random.choice(scale_bins)) if self.anisotropic
+                         else random.choice(scale_bins))
+                recon, posterior = self.forward(images, wvs, scale=scale, angle=angle, noise=noise)
+                target = ops.area_rot(images, recon.shape[-2:], angle)  # area resize + rot90, one kernel
+            elif random.random() < self.p_prior_s:  # prior preservation (:621-627)
+                recon, posterior = self.forward(images, wvs, scale=random.choice(scale_bins), noise=noise)
+                target = ops.area_rot(images, recon.shape[-2:], None)
+            else:
+                recon, posterior = self.forward(images, wvs, noise=noise)
 
-        opt_gen.zero_grad()
-        loss_kwargs = dict(inputs=target, wvs=wvs, reconstructions=recon, optimizer_idx=0,
-                           global_step=self.global_step, last_layer=self.get_last_layer(), split='train')
-        if getattr(self.loss_fn, 'weights', {}).get('kl', 0) > 0:
-            loss_kwargs['posterior'] = posterior
-        gen_loss, logs = self.loss_fn(**loss_kwargs)
-        self.manual_backward(gen_loss)
+            opt_gen.zero_grad()
+            loss_kwargs = dict(inputs=target, wvs=wvs, reconstructions=recon, optimizer_idx=0,
+                               global_step=self.global_step, last_layer=self.get_last_layer(), split='train')
+            if getattr(self.loss_fn, 'weights', {}).get('kl', 0) > 0:
+                loss_kwargs['posterior'] = posterior
+            gen_loss, logs = self.loss_fn(**loss_kwargs)
+            self.manual_backward(gen_loss)
+        finally:
+            ops.WeightPrepack.release()   # the packs belong to THIS step's weights, whatever happens in it
         if self.clip_grad:
             logs['train/grad_norm'] = self._clip(opt_gen)
         opt_gen.step()

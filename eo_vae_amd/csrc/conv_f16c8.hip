@@ -1472,6 +1472,7 @@ __global__ void absmax_part_kernel(const float* __restrict__ x, size_t n, float*
   }
 }
 
+__device__ __forceinline__ int cdiv_d(int a, int b) { return (a + b - 1) / b; }
 constexpr int PACK_PARTS = 256;   // amax partials kept behind the header of a packed weight buffer
 
 // w[Cout][Cin][9] fp32 -> per (tap, 32-ch chunk, 128-co block) one 16 KiB tile:
@@ -1479,9 +1480,10 @@ constexpr int PACK_PARTS = 256;   // amax partials kept behind the header of a p
 //   [8 KiB, 16 KiB) e4m3 [wh' | wl'][half 0..1][128 m][16 k]
 // flip = 0: k = ci, m = co;  flip = 1 (data gradient): k = co, m = ci, taps reversed.
 // One thread = 4 consecutive k of one (tile, m): one dword of each fp8 image, 8 bytes of the f16 image.
-__global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp, int Cout, int Cin,
-                                  int nchunk, int ncob, int flip, float scale, const float* __restrict__ parts,
-                                  int nparts, unsigned* __restrict__ hdr) {
+__device__ __forceinline__ void pack_f16c8_body(const float* __restrict__ w, unsigned char* __restrict__ wp, int Cout,
+                                                int Cin, int nchunk, int ncob, int flip, float scale,
+                                                const float* __restrict__ parts, int nparts, unsigned* __restrict__ hdr,
+                                                unsigned bid, unsigned nblk) {
   // amax(|w|) of the UNSCALED weights = max of the partial maxima absmax_part_kernel left behind the header
   // (every block folds the <= 256 numbers itself: no fold launch, no zero-filled atomic target); `scale` is a
   // power of two.  Block 0 publishes the bits in this buffer's header for the convolution kernel.
@@ -1494,13 +1496,12 @@ __global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __
   }
   const float wmax = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
   const unsigned wbits = __builtin_bit_cast(unsigned, wmax);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = wbits;
+  if (bid == 0 && threadIdx.x == 0) *hdr = wbits;
   const float amax = wmax * fabsf(scale);
   const int e1 = amax > 0.f ? 7 - expo_of_bits(__builtin_bit_cast(unsigned, amax)) : 0;
   const float s_hi = pow2f(e1), s_lo = pow2f(e1 + 12);   // |wl| <= 2^-11 |w|: wl * s_lo stays under 256
   const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = bid * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
     const int k4 = i & 7;
     size_t t = i >> 3;
     const int m_ = t & 127;
@@ -1532,6 +1533,49 @@ __global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __
     *reinterpret_cast<int*>(p8) = w_hi;
     *reinterpret_cast<int*>(p8 + 2 * 128 * 16) = w_lo;
   }
+}
+
+__global__ void pack_f16c8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp, int Cout, int Cin,
+                                  int nchunk, int ncob, int flip, float scale, const float* __restrict__ parts,
+                                  int nparts, unsigned* __restrict__ hdr) {
+  pack_f16c8_body(w, wp, Cout, Cin, nchunk, ncob, flip, scale, parts, nparts, hdr, blockIdx.x, gridDim.x);
+}
+
+// Every plain 3x3 layer of a model in TWO launches per step instead of three per layer (176 launches of 5-10 us each
+// in the full-size model): blockIdx.y = layer (x orientation).  Descriptors live in device memory.
+struct PackDesc {
+  const float* w;
+  unsigned char* wp_fwd;
+  unsigned char* wp_bwd;
+  int Cout, Cin;
+};
+constexpr int PACK_MULTI_PARTS = 64;
+__device__ __forceinline__ float* pack_parts_of(const PackDesc& d) {   // behind the header of the forward buffer
+  return reinterpret_cast<float*>(d.wp_fwd + (size_t)9 * cdiv_d(d.Cin, 32) * cdiv_d(d.Cout, 128) * 16384 + 16);
+}
+__global__ __launch_bounds__(256) void pack_multi_amax_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const size_t n = (size_t)d.Cout * d.Cin * 9;
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)PACK_MULTI_PARTS * 256) m = fmaxf(m, fabsf(d.w[i]));
+  m = wave_max(m);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    pack_parts_of(d)[blockIdx.x] = (m < 3.0e38f) ? m : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ descs, float scale) {
+  const PackDesc d = descs[blockIdx.y >> 1];
+  const int flip = blockIdx.y & 1;
+  const int k = flip ? d.Cout : d.Cin, m = flip ? d.Cin : d.Cout;
+  const int nchunk = cdiv_d(k, 32), ncob = cdiv_d(m, 128);
+  unsigned char* base = flip ? d.wp_bwd : d.wp_fwd;
+  unsigned* hdr = reinterpret_cast<unsigned*>(base + (size_t)9 * nchunk * ncob * 16384);
+  pack_f16c8_body(d.w, base, d.Cout, d.Cin, nchunk, ncob, flip, scale, pack_parts_of(d), PACK_MULTI_PARTS, hdr, blockIdx.x,
+                  gridDim.x);
 }
 
 }  // namespace
@@ -1620,6 +1664,19 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
   launch(b0, nch0, ncb0, 0, hdr0);
   launch(b1, nch1, ncb1, 1, hdr1);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack_pair");
+  return EOVAE_OK;
+}
+
+// All plain 3x3 layers of a model at once.  descs: DEVICE array of n records {const float* w; void* wp_fwd; void* wp_bwd;
+// int Cout; int Cin;} (32 bytes each, buffers sized by eovae_conv3x3_f16c8_packed_bytes(Cout, Cin, 0 / 1)); the result
+// is what n calls of eovae_conv3x3_f16c8_pack_pair produce, in two launches.
+int eovae_conv3x3_f16c8_pack_multi(const void* descs, int n, float scale, void* stream) {
+  EOVAE_CHECK_ARG(descs && n > 0 && n <= 32767, "conv3x3_f16c8_pack_multi: bad argument");
+  static_assert(sizeof(PackDesc) == 32, "PackDesc layout is part of the ABI");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pack_multi_amax_kernel, dim3(PACK_MULTI_PARTS, n), dim3(256), 0, st, (const PackDesc*)descs);
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(96, 2 * n), dim3(256), 0, st, (const PackDesc*)descs, scale);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack_multi");
   return EOVAE_OK;
 }
 

@@ -347,8 +347,57 @@ def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, p
         ev1.record()
 
 
+class WeightPrepack:
+    """Forward and data-gradient f16c8 packs of EVERY plain 3x3 layer of a model from two launches per step
+    (eovae_conv3x3_f16c8_pack_multi) instead of three launches per layer.  The packs are only trusted between
+    `run()` and `release()` of the same training step (EOFluxVAE.training_step): nothing is cached across optimiser
+    steps, and a weight whose storage moved since the descriptors were built makes `stale()` true."""
+
+    def __init__(self, weights):
+        import numpy as np
+        lib = L.load()
+        self.weights = [w for w in weights if w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
+                        and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and w.dtype == torch.float32 and w.is_contiguous()]
+        self.packs, rows = {}, []
+        for w in self.weights:
+            cout, cin = w.shape[0], w.shape[1]
+            wp0 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device=w.device)
+            wp1 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 1), dtype=torch.uint8, device=w.device)
+            self.packs[w.data_ptr()] = (wp0, wp1)
+            rows.append((w.data_ptr(), wp0.data_ptr(), wp1.data_ptr(), cout, cin))
+        desc = np.zeros(len(rows), dtype=np.dtype([('w', '<u8'), ('p0', '<u8'), ('p1', '<u8'), ('co', '<i4'), ('ci', '<i4')]))
+        for i, r in enumerate(rows):
+            desc[i] = r
+        self.ptrs = [r[0] for r in rows]
+        self.desc = (torch.from_numpy(desc.view(np.uint8).copy()).to(self.weights[0].device) if rows else None)
+
+    def stale(self):
+        return [w.data_ptr() for w in self.weights] != self.ptrs
+
+    def run(self):
+        global _ACTIVE_PREPACK
+        if self.desc is None:
+            return
+        L.check(L.load().eovae_conv3x3_f16c8_pack_multi(L.ptr(self.desc), len(self.ptrs), 1.0, L.stream()),
+                'eovae_conv3x3_f16c8_pack_multi')
+        _ACTIVE_PREPACK = self.packs
+
+    @staticmethod
+    def release():
+        global _ACTIVE_PREPACK
+        _ACTIVE_PREPACK = None
+
+
+_ACTIVE_PREPACK = None
+PREPACK = os.environ.get('EOVAE_PREPACK', '1') != '0'
+
+
 def pack_pair_f16c8(weight):
     """(forward, data-gradient) f16c8 weight packs of one plain 3x3 layer from ONE amax pass."""
+    if _ACTIVE_PREPACK is not None:
+        hit = _ACTIVE_PREPACK.get(weight.data_ptr())
+        if hit is not None:
+            return hit
     lib = L.load()
     cout, cin = weight.shape[0], weight.shape[1]
     wp0 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device=weight.device)

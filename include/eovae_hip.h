@@ -83,6 +83,10 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
 /* both orientations (flip 0 into wp_fwd, flip 1 into wp_bwd) from one amax pass */
 int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, int Cout, int Cin, float scale,
                                   void* stream);
+/* Every plain 3x3 layer of a model at once (two launches instead of three per layer).  descs: DEVICE array of n
+ * 32-byte records { const float* w; void* wp_fwd; void* wp_bwd; int Cout; int Cin; }, buffers sized by
+ * eovae_conv3x3_f16c8_packed_bytes(Cout, Cin, 0 / 1); result = n calls of eovae_conv3x3_f16c8_pack_pair. */
+int eovae_conv3x3_f16c8_pack_multi(const void* descs, int n, float scale, void* stream);
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual,
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,

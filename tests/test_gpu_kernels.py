@@ -327,3 +327,36 @@ def test_plain_weight_gradient_is_bit_reproducible(n, cin, cout, h, w, packed):
         assert rel_err(d1, a1) < 2e-6 and rel_err(b1, ba) < 2e-6
     finally:
         ops.CONV_PRECISION = old
+
+
+def test_weight_prepack_equals_the_per_layer_packs():
+    """ops.WeightPrepack (two launches for all plain 3x3 layers) writes the bytes the per-layer pack_pair calls write:
+    tiles and the amax header (the scratch behind the header holds the amax partials and may differ)."""
+    from eo_vae_amd import lib as L, ops
+    lib = L.load()
+    shapes = [(128, 128), (256, 128), (64, 512), (512, 512), (96, 32)]
+    ws = [hashed((co, ci, 3, 3), 400 + i, (i + 1) * 0.1 / (ci * 9) ** 0.5).cuda() for i, (co, ci) in enumerate(shapes)]
+    ws[2].mul_(1e-3)                           # different amax per layer
+    pp = ops.WeightPrepack(ws)
+    assert len(pp.weights) == len(ws) and not pp.stale()
+    pp.run()
+    torch.cuda.synchronize()
+    try:
+        for w in ws:
+            got0, got1 = ops.pack_pair_f16c8(w)            # served from the prepack
+            assert got0.data_ptr() == pp.packs[w.data_ptr()][0].data_ptr()
+        ops.WeightPrepack.release()
+        for w in ws:
+            co, ci = w.shape[0], w.shape[1]
+            ref0, ref1 = ops.pack_pair_f16c8(w)            # the per-layer launches
+            torch.cuda.synchronize()
+            got0, got1 = pp.packs[w.data_ptr()]
+            assert ref0.data_ptr() != got0.data_ptr()
+            for flip, (ref, got) in enumerate(((ref0, got0), (ref1, got1))):
+                nb = lib.eovae_conv3x3_f16c8_packed_bytes(co, ci, flip) - 256 * 4 - 12   # tiles + the header word
+                assert torch.equal(ref[:nb], got[:nb]), (co, ci, flip)
+    finally:
+        ops.WeightPrepack.release()
+    ws[1] = ws[1].clone()                      # a weight whose storage moved
+    pp.weights[1] = ws[1]
+    assert pp.stale()
