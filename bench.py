@@ -53,7 +53,10 @@ def pmc_traffic(kernel):
     null and the source says why -- a stale file is never passed off as a measurement."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))   # by round tag (mtimes do not travel)
-    for f in reversed(files):
+    from eo_vae_amd import ops
+    build = csrc_digest()
+    newest = None
+    for f in reversed(files):   # newest tag first; the fold that was measured on THIS build and mode wins
         try:
             with open(f) as fh:
                 d = json.load(fh)
@@ -62,19 +65,19 @@ def pmc_traffic(kernel):
         k = d.get('kernels', {}).get(kernel)
         if k is None:
             continue
-        src = {'file': os.path.relpath(f, ROOT), 'csrc_digest': d.get('csrc_digest'), 'build_digest': csrc_digest(),
+        src = {'file': os.path.relpath(f, ROOT), 'csrc_digest': d.get('csrc_digest'), 'build_digest': build,
                'fetch_bytes_raw': k.get('fetch_bytes_raw_per_launch'), 'write_bytes': k.get('write_bytes_per_launch'),
                'note': 'FETCH_SIZE x2 (gfx950 correction, calibrated for 16-B/lane streams; halo loads are dword/lane, '
                        'so the true figure lies between raw and corrected)'}
-        from eo_vae_amd import ops
-        if d.get('conv_precision', ops.DEFAULT_PRECISION) != ops.CONV_PRECISION:
-            src['stale'] = (f"fold measured in conv precision {d.get('conv_precision', ops.DEFAULT_PRECISION)!r}, "
-                            f'this run is {ops.CONV_PRECISION!r}')
-            return None, src
-        if d.get('csrc_digest') == src['build_digest']:
+        prec = d.get('conv_precision', ops.DEFAULT_PRECISION)
+        if prec == ops.CONV_PRECISION and d.get('csrc_digest') == build:
             return k['traffic_bytes_per_launch_corrected'], src
-        src['stale'] = 'kernel sources changed since this fold was measured'
-        return None, src
+        if newest is None:
+            src['stale'] = (f'fold measured in conv precision {prec!r}, this run is {ops.CONV_PRECISION!r}'
+                            if prec != ops.CONV_PRECISION else 'kernel sources changed since this fold was measured')
+            newest = src
+    if newest is not None:
+        return None, newest
     return None, {'file': None, 'note': 'no PMC fold for this kernel under profiles/'}
 
 
