@@ -18,18 +18,26 @@ def sample_index(numel, k=16):
     return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
 
 
-def full_step_errors(prod, g=None):
+FULL_STEP_CASES = {   # fixture -> (modality, seed of the synthetic batch); tests/golden/gen_golden.py full_step / full_step12
+    'full_cfg2_step': ('S2RGB', 1234),
+    'full_cfg3_step': ('S2L2A', 1236),
+}
+
+
+def full_step_errors(prod, g=None, case='full_cfg2_step'):
     """One full-size train-mode forward + backward of the product model `prod` (on cuda, filled with
-    det_fill(seed=31)) against tests/golden/full_cfg2_step.npz, which gen_golden.py wrote by running the
+    det_fill(seed=31)) against tests/golden/<case>.npz, which gen_golden.py wrote by running the
     REFERENCE (new_autoencoder.py:587-690: forward with the injected posterior noise, Charbonnier + 1e-6 KL,
-    backward; B=2, S2RGB 256x256).  Returns relative errors of the loss scalars, the reconstruction, the global
+    backward; B=2, 256x256; `full_cfg2_step` = S2RGB, `full_cfg3_step` = S2L2A with its 12-channel dynamic
+    convolutions).  Returns relative errors of the loss scalars, the reconstruction, the global
     gradient norm and -- per parameter tensor -- the gradient's L2 norm and 16 sampled entries."""
     from eo_vae_amd import ops
     if g is None:
-        g = dict(np.load(os.path.join(GOLDEN, 'full_cfg2_step.npz'), allow_pickle=False))
+        g = dict(np.load(os.path.join(GOLDEN, case + '.npz'), allow_pickle=False))
+    modality, seed = FULL_STEP_CASES[case]
     prod.train()
-    wvs = torch.tensor(O.WAVELENGTHS['S2RGB']).cuda()
-    x = O.synthetic_batch(2, 3, 256, seed=1234)
+    wvs = torch.tensor(O.WAVELENGTHS[modality]).cuda()
+    x = O.synthetic_batch(2, len(O.WAVELENGTHS[modality]), 256, seed=seed)
     assert abs(float(x.double().sum()) - float(g['x_checksum'])) < 1e-6 * abs(float(g['x_checksum'])) + 1e-6
     x = x.cuda()
     for p in prod.parameters():
@@ -77,4 +85,32 @@ def full_step_errors(prod, g=None):
                                     / np.abs(g['bn_running_var']).max()))
     for p in prod.parameters():
         p.grad = None
+    return out
+
+
+def full_encode_errors(prod, g=None):
+    """cfg5's path at full size against tests/golden/full_cfg5_encode.npz (gen_golden.py full_encode: the REFERENCE's
+    encode_spatial_normalized, new_autoencoder.py:480-502, on two S2L2A batches of 2 x 12 x 256 x 256, then
+    RunningStatsButFast, encode_latents.py:65-94).  `prod` = product model on cuda filled with det_fill(seed=31)."""
+    from eo_vae_amd.encode_latents import RunningStats
+    if g is None:
+        g = dict(np.load(os.path.join(GOLDEN, 'full_cfg5_encode.npz'), allow_pickle=False))
+    prod.eval()
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A']).cuda()
+    stats = RunningStats(32, device='cuda')
+    out = {}
+    for i in range(2):
+        x = O.synthetic_batch(2, 12, 256, seed=1240 + i)
+        assert abs(float(x.double().sum()) - float(g[f'x_checksum{i}'])) < 1e-6 * abs(float(g[f'x_checksum{i}'])) + 1e-6
+        with torch.no_grad():
+            z = prod.encode_spatial_normalized(x.cuda(), wvs)
+        stats.update(z)
+        ref = torch.from_numpy(g[f'z_sub{i}']).double()
+        out[f'latent{i}_max_rel_err'] = float((z[:, :, ::2, ::2].double().cpu() - ref).abs().max() / ref.abs().max())
+    torch.cuda.synchronize()
+    sd = stats.get_stats_dict()
+    for k in ['mean', 'var', 'std', 'min', 'max', 'count']:
+        mine = torch.as_tensor(sd[k]).detach().double().cpu().reshape(-1).numpy()
+        ref = g['stats_' + k].astype(np.float64).reshape(-1)
+        out[f'stats_{k}_rel_err'] = float(np.abs(mine - ref).max() / max(np.abs(ref).max(), 1e-30))
     return out

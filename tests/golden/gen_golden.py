@@ -411,6 +411,99 @@ def full_step(R):
          grad_norms=norms, grad_samples=samples, bn_running_mean=bn_mean, bn_running_var=bn_var)
 
 
+def full_step12(R):
+    """cfg3's arithmetic path at FULL size on the reference itself: the same train step as
+    full_step, on S2L2A (12 wavelengths, terramesh_datamodule.py:21-34), B=2, 256x256.  At C = 12 the first / last
+    layers are 12-channel dynamic convolutions (new_autoencoder.py:587-690 -> dynamic_conv.py:499-535, 666-710).
+    Loss = Charbonnier + 1e-6 KL as in full_step (L1 stored beside it: its sign() gradient flips on round-off,
+    DESIGN.md s2).  The MS-SSIM term of cfg3 is NOT part of this fixture: consistency_loss.py:6 imports torchmetrics,
+    which is not installed ("parity unpinned")."""
+    print('full-size cfg3 train-step fixture (B=2, S2L2A 12 ch, 256x256, forward + backward) -- takes ~2 min')
+    from einops import rearrange
+    F = torch.nn.functional
+    cfg = O.model_cfg()
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    O.det_fill(ref, seed=31)
+    ref.train()
+    ns = {'torch': torch, 'nn': torch.nn, 'F': F}
+    Charb = ref_class_from_source(os.path.join(REF, 'eo_vae/models/modules/consistency_loss.py'),
+                                  'CharbonnierLoss', ns)
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    assert wvs.numel() == 12
+    x = O.synthetic_batch(2, 12, 256, seed=1236)
+    eps = hashed((2, 32, 32, 32), 1612, 1.0)
+    post = ref.encode(x, wvs)
+    z = post.mean + post.std * eps
+    zs = rearrange(z, '... c (i pi) (j pj) -> ... (c pi pj) i j', pi=2, pj=2)
+    recon = ref.decode(ref._normalize_latent(zs), wvs)
+    char = Charb()(recon, x)
+    l1 = F.l1_loss(recon, x)
+    kl = post.kl()
+    loss = char + 1e-6 * kl.mean()
+    loss.backward()
+    named = [('encoder.' + k, p) for k, p in ref.encoder.named_parameters()] + \
+            [('decoder.' + k, p) for k, p in ref.decoder.named_parameters()]
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)))
+    names = np.array([k for k, _ in named])
+    norms = np.array([p.grad.double().norm().item() for _, p in named])
+    samples = np.stack([npy(p.grad).reshape(-1)[sample_index(p.numel())] for _, p in named])
+    bn_mean, bn_var = npy(ref.bn.running_mean), npy(ref.bn.running_var)
+    mine = O.build_vae(cfg)
+    O.det_fill(mine, seed=31)
+    mine.train()
+    rec_o, post_o = mine(x, wvs, noise=eps)
+    loss_o = O.charbonnier(rec_o, x) + 1e-6 * post_o.kl().mean()
+    loss_o.backward()
+    close(rec_o, recon, 1e-4, 'full_step12.recon')
+    close(loss_o, loss, 2e-5, 'full_step12.loss')
+    po = dict(mine.named_parameters())
+    worst = 0.0
+    for (k, p), n in zip(named, norms):
+        err = (po[k].grad.double() - p.grad.double()).norm().item()
+        worst = max(worst, err / max(n, 1e-3 * gnorm))
+    assert worst < 2e-4, f'oracle != reference for full_step12 gradients: {worst}'
+    print(f'  oracle vs reference: worst per-tensor gradient error {worst:.2e}')
+    save('full_cfg3_step', x_checksum=np.float64(x.double().sum().item()), eps=npy(eps),
+         recon_sub=npy(recon[:, :, ::8, ::8]), loss=np.float64(loss.item()), charbonnier=np.float64(char.item()),
+         l1=np.float64(l1.item()), kl=npy(kl), grad_norm=np.float64(gnorm), grad_names=names,
+         grad_norms=norms, grad_samples=samples, bn_running_mean=bn_mean, bn_running_var=bn_var)
+
+
+def full_encode(R):
+    """cfg5's path at FULL size on the reference itself: encode_latents.py:160-169 (`encode_spatial_norm` =
+    EOFluxVAE.encode_spatial_normalized, new_autoencoder.py:480-502) on two S2L2A batches of 2 x 12 x 256 x 256,
+    then RunningStatsButFast (encode_latents.py:65-94) over the two latent batches."""
+    print('full-size cfg5 encode fixture (2 batches of B=2, S2L2A, 256x256) -- takes ~30 s')
+    cfg = O.model_cfg()
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    O.det_fill(ref, seed=31)
+    ref.eval()
+    ns = {'torch': torch, 'nn': torch.nn}
+    Ref = ref_class_from_source(os.path.join(REF, 'encode_latents.py'), 'RunningStatsButFast', ns)
+    stats, mine_stats = Ref((32,), [0, 2, 3]), O.RunningStats(32)
+    mine = O.build_vae(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine.eval()
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    arrays = {}
+    for i in range(2):
+        x = O.synthetic_batch(2, 12, 256, seed=1240 + i)
+        with torch.no_grad():
+            z = ref.encode_spatial_normalized(x, wvs)
+            close(mine.encode_spatial_normalized(x, wvs), z, 1e-4, f'full_encode.z{i}')
+        assert tuple(z.shape) == (2, 32, 32, 32), z.shape
+        stats(z)
+        mine_stats.update(z)
+        arrays[f'x_checksum{i}'] = np.float64(x.double().sum().item())
+        arrays[f'z_sub{i}'] = npy(z[:, :, ::2, ::2])
+    for k in ['mean', 'var', 'std', 'min', 'max', 'count']:
+        close(getattr(mine_stats, k), getattr(stats, k), 1e-6, 'full_encode.stats.' + k)
+        arrays['stats_' + k] = npy(getattr(stats, k))
+    save('full_cfg5_encode', **arrays)
+
+
 def extra_losses(R):
     """SAM / gradient-difference / focal-frequency branches of EOConsistencyLoss.
     consistency_loss.py cannot be imported as a whole (top-level torchmetrics import), so its
@@ -633,7 +726,8 @@ if __name__ == '__main__':
               ('extra_losses', lambda: extra_losses(R)), ('eqvae', lambda: eqvae(R)),
               ('distill', lambda: distill(R)),
               ('running_stats', running_stats), ('batch_prep', batch_prep),
-              ('full_size', lambda: full_size(R)), ('full_step', lambda: full_step(R))]
+              ('full_size', lambda: full_size(R)), ('full_step', lambda: full_step(R)),
+              ('full_step12', lambda: full_step12(R)), ('full_encode', lambda: full_encode(R))]
     for name, fn in groups:
         if not only or name in only:
             fn()

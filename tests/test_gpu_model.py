@@ -216,6 +216,49 @@ def test_full_size_train_step_against_reference(golden, mode):
         ops.CONV_PRECISION = old
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16c8'])
+def test_full_size_s2l2a_train_step_against_reference(golden, mode):
+    """the 12-wavelength path at FULL size against the REFERENCE (fixture `full_cfg3_step`, B=2, S2L2A
+    256x256).  At C = 12 the first / last layers leave the thin fp32 kernels for conv3x3_bf16_kernel /
+    wgrad3x3_bf16_kernel (K % 32 != 0), which no other full-size fixture touches.  Same bars as the S2RGB step.
+    (cfg3's MS-SSIM term is not in the fixture: torchmetrics is absent, parity unpinned.)"""
+    from eo_vae_amd import ops
+    from oracle.parity_checks import full_step_errors
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, mode
+    try:
+        _, prod = build_pair({}, 31)
+        e = full_step_errors(prod, golden('full_cfg3_step'), case='full_cfg3_step')
+        print(mode, e)
+        assert e['loss_rel_err'] <= REL_LOSS and e['charbonnier_rel_err'] <= REL_LOSS and e['l1_rel_err'] <= REL_LOSS, e
+        assert e['recon_max_rel_err'] <= REL_OUT and e['kl_max_rel_err'] <= REL_OUT, e
+        assert e['grad_norm_rel_err'] <= REL_OUT, e
+        bar = grad_bar()
+        assert e['grad_worst_norm_rel_err'] <= bar and e['grad_worst_sample_rel_err'] <= 4 * bar, e
+        assert e['bn_mean_rel_err'] <= stat_bar() and e['bn_var_rel_err'] <= stat_bar(), e
+    finally:
+        ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16c8'])
+def test_full_size_encode_only_against_reference(golden, mode):
+    """cfg5's path at FULL size against the REFERENCE (fixture `full_cfg5_encode`): two S2L2A batches
+    through encode_spatial_normalized (new_autoencoder.py:480-502) and the running latent statistics
+    (encode_latents.py:65-94).  Latents 1e-3 (north_star); statistics this repository's own bar."""
+    from eo_vae_amd import ops
+    from oracle.parity_checks import full_encode_errors
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, mode
+    try:
+        _, prod = build_pair({}, 31)
+        e = full_encode_errors(prod, golden('full_cfg5_encode'))
+        print(mode, e)
+        assert e['latent0_max_rel_err'] <= REL_OUT and e['latent1_max_rel_err'] <= REL_OUT, e
+        for k in ['mean', 'var', 'std', 'min', 'max']:
+            assert e[f'stats_{k}_rel_err'] <= REL_OUT, (k, e)
+        assert e['stats_count_rel_err'] == 0.0, e
+    finally:
+        ops.CONV_PRECISION = old
+
+
 def test_noise_prefetch_reproduces_the_in_sample_draw():
     """the posterior noise is drawn on the CPU generator BEFORE the encoder is enqueued (pinned double buffer,
     non-blocking copy).  Seeded, it must be bit-identical to the reference-style draw inside sample() -- first call

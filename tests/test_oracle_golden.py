@@ -194,6 +194,48 @@ def test_full_cfg2_step_fixture(golden):
         assert abs(got - n) <= 2e-4 * max(n, 1e-3 * tot), (k, got, n)
 
 
+def test_full_cfg3_step_fixture(golden):
+    """BASELINE config 3's arithmetic path at full size (B=2, S2L2A: 12-channel dynamic convolutions first and last):
+    the oracle's forward + backward against the fixture the REFERENCE wrote (gen_golden.py full_step12).  The MS-SSIM
+    term is not in the fixture (torchmetrics absent: parity unpinned) -- ~60 s on 8 threads."""
+    g = golden('full_cfg3_step')
+    torch.set_num_threads(8)
+    m = O.build_vae(O.model_cfg()).train()
+    O.det_fill(m, seed=31)
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    x = O.synthetic_batch(2, 12, 256, seed=1236)
+    assert abs(x.double().sum().item() - float(g['x_checksum'])) < 1e-6 * abs(float(g['x_checksum'])) + 1e-6
+    rec, post = m(x, wvs, noise=torch.from_numpy(g['eps']))
+    loss = O.charbonnier(rec, x) + 1e-6 * post.kl().mean()
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 2e-5 * abs(float(g['loss']))
+    assert_close(rec[:, :, ::8, ::8], g['recon_sub'], 1e-4, 'recon')
+    po = dict(m.named_parameters())
+    tot = float(g['grad_norm'])
+    for k, n in zip(g['grad_names'], g['grad_norms']):
+        got = po[str(k)].grad.double().norm().item()
+        assert abs(got - n) <= 2e-4 * max(n, 1e-3 * tot), (k, got, n)
+
+
+def test_full_cfg5_encode_fixture(golden):
+    """BASELINE config 5's path at full size: encode_spatial_normalized on two S2L2A batches + RunningStatsButFast,
+    oracle against the fixture the REFERENCE wrote (gen_golden.py full_encode)."""
+    g = golden('full_cfg5_encode')
+    torch.set_num_threads(8)
+    m = O.build_vae(O.model_cfg()).eval()
+    O.det_fill(m, seed=31)
+    wvs = torch.tensor(O.WAVELENGTHS['S2L2A'])
+    rs = O.RunningStats(32)
+    for i in range(2):
+        x = O.synthetic_batch(2, 12, 256, seed=1240 + i)
+        with torch.no_grad():
+            z = m.encode_spatial_normalized(x, wvs)
+        assert_close(z[:, :, ::2, ::2], g[f'z_sub{i}'], 1e-4, f'z{i}')
+        rs.update(z)
+    for k in ['mean', 'var', 'std', 'min', 'max', 'count']:
+        assert_close(getattr(rs, k), g['stats_' + k], 1e-5, k)
+
+
 # ---- MS-SSIM: PARITY UNPINNED (torchmetrics absent) -> known-answer properties (SURVEY 8c) ----
 
 def test_msssim_properties():
