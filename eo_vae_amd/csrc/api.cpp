@@ -12,8 +12,57 @@ void eovae_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Run-time switches (kernel selection for A/B runs and tests).  Each starts from its environment variable, read ONCE at
+// first use; after that only eovae_set_option changes it -- no getenv on a launch path, and a test flips a kernel
+// through the ABI instead of mutating os.environ under a running launch.
+#include <atomic>
+#include <stdlib.h>
+#include "eovae_common.h"
+namespace {
+struct OptDef { const char* name; const char* env; int dflt; };
+const OptDef kOpts[EOVAE_OPT_COUNT] = {
+    {"c8_wgrad_rows", "EOVAE_C8_WGRAD_ROWS", 1},   // row-streaming weight gradient (conv_f16c8_wgrad_rows.hip)
+};
+std::atomic<int> g_opt[EOVAE_OPT_COUNT];
+std::atomic<int> g_opt_init{0};
+void opt_init() {
+  if (g_opt_init.load(std::memory_order_acquire) == 2) return;
+  int expect = 0;
+  if (g_opt_init.compare_exchange_strong(expect, 1)) {
+    for (int i = 0; i < EOVAE_OPT_COUNT; ++i) {
+      const char* e = getenv(kOpts[i].env);
+      g_opt[i].store(e && *e ? atoi(e) : kOpts[i].dflt, std::memory_order_relaxed);
+    }
+    g_opt_init.store(2, std::memory_order_release);
+  } else {
+    while (g_opt_init.load(std::memory_order_acquire) != 2) {}
+  }
+}
+}  // namespace
+int eovae_opt(int id) {
+  opt_init();
+  return (id >= 0 && id < EOVAE_OPT_COUNT) ? g_opt[id].load(std::memory_order_relaxed) : 0;
+}
+
 extern "C" {
 const char* eovae_last_error(void) { return g_err; }
-int eovae_abi_version(void) { return 8; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad
+int eovae_set_option(const char* name, int value) {
+  opt_init();
+  for (int i = 0; name && i < EOVAE_OPT_COUNT; ++i)
+    if (strcmp(name, kOpts[i].name) == 0) {
+      g_opt[i].store(value, std::memory_order_relaxed);
+      return EOVAE_OK;
+    }
+  eovae_set_error("eovae_set_option: unknown option '%s'", name ? name : "(null)");
+  return EOVAE_ERR_ARG;
+}
+int eovae_get_option(const char* name) {
+  opt_init();
+  for (int i = 0; name && i < EOVAE_OPT_COUNT; ++i)
+    if (strcmp(name, kOpts[i].name) == 0) return g_opt[i].load(std::memory_order_relaxed);
+  eovae_set_error("eovae_get_option: unknown option '%s'", name ? name : "(null)");
+  return EOVAE_ERR_ARG;
+}
+int eovae_abi_version(void) { return 9; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

@@ -1850,12 +1850,18 @@ static int c8_wgrad_impl(const float* x, const float* dy, float* dwp, float* par
   dim3 grid(a.ncib * ncob * split);
   hipStream_t st = (hipStream_t)stream;
   a.xpacked = xpacked;
+  a.nseg = 1; a.units = 0;
   // one-wave-per-SIMD kernel (conv_f16c8_wgrad_w4.hip) for plain layers made of full tiles
   if (!part && eovae_c8_wgrad_w4_eligible(a)) {
     eovae_c8_wgrad_w4_launch(a, st);
     EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad (w4)");
     return EOVAE_OK;
   }
+  // row-streaming kernel (conv_f16c8_wgrad_rows.hip): plain layers with record input and partial-tile output
+  if (eovae_c8_wgrad_rows_eligible(a)) {
+    eovae_c8_wgrad_rows_launch(a, st);
+    split = a.split;
+  } else
   if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1, false>), grid, dim3(512), 0, st, a);
   else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2, false>), grid, dim3(512), 0, st, a);
   else if (xpacked) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, true>), grid, dim3(512), 0, st, a);

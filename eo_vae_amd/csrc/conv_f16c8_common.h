@@ -39,6 +39,7 @@ struct WgCArgs {
   int ncob_, split, xcd_remap;
   int xpacked;              // x = f16c8 operand records (GroupNorm-apply)
   float* part;              // plain layers: per-block partial sums [slab][split][9][128][64] instead of atomics into dwp (or null)
+  int nseg, units;          // conv_f16c8_wgrad_rows.hip: row segments per strip, units (image x strip x segment) of the walk
 };
 
 namespace {
@@ -72,6 +73,11 @@ __device__ __forceinline__ int expo_of_bits(unsigned bits) {
 // (plain 3x3 form, full 16 x 32 tiles only); returns false when the layer does not qualify.
 bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu);
 void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st);
+
+// conv_f16c8_wgrad_rows.hip: row-streaming weight gradient (plain 3x3 form, record input, partial-tile output); the
+// launch fills a.nseg / a.units and may lower a.split (blocks per slab) to the number of units
+bool eovae_c8_wgrad_rows_eligible(const WgCArgs& a);
+void eovae_c8_wgrad_rows_launch(WgCArgs& a, hipStream_t st);
 
 // conv_f16c8_wgrad_w4.hip: one-wave-per-SIMD weight gradient (plain 3x3 form, full tiles)
 bool eovae_c8_wgrad_w4_eligible(const WgCArgs& a);

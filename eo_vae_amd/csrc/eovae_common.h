@@ -9,6 +9,11 @@
 #define EOVAE_ERR_LAUNCH (-2)
 #define EOVAE_ERR_UNSUPPORTED (-3)
 
+// run-time switches (api.cpp): value of option `id`, initialised once from its environment variable, changed only by
+// eovae_set_option
+enum { EOVAE_OPT_WGRAD_ROWS = 0, EOVAE_OPT_COUNT };
+int eovae_opt(int id);
+
 // thread-local last-error text, exported through eovae_last_error()
 void eovae_set_error(const char* fmt, ...);
 

@@ -21,6 +21,8 @@ SIGNATURES = {
     'eovae_last_error': (C.c_char_p, []),
     'eovae_abi_version': (_i, []),
     'eovae_target_arch': (C.c_char_p, []),
+    'eovae_set_option': (_i, [C.c_char_p, _i]),
+    'eovae_get_option': (_i, [C.c_char_p]),
     'eovae_conv_packed_dims': (_i, [_i, _i, _i, _i, _i, _ip, _ip]),
     'eovae_conv_pack_weights': (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     'eovae_conv2d_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
@@ -94,7 +96,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 9  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

@@ -28,6 +28,12 @@ extern "C" {
 const char* eovae_last_error(void);
 int eovae_abi_version(void);
 const char* eovae_target_arch(void); /* "gfx950" */
+/* Run-time switches for A/B runs and tests (kernel selection only -- never arithmetic).  Each option starts from its
+ * environment variable, read once; afterwards only eovae_set_option changes it.  Returns 0 / the value, or a negative
+ * status for an unknown name.  Options: "c8_wgrad_rows" (EOVAE_C8_WGRAD_ROWS, default 1): plain 3x3 weight gradients
+ * with record input run the row-streaming kernel instead of the tile kernel. */
+int eovae_set_option(const char* name, int value);
+int eovae_get_option(const char* name);
 
 /* ----------------------------------------------------------------------------------------
  * Convolution = implicit GEMM on the matrix cores (csrc/conv_f32.hip)

@@ -1,0 +1,76 @@
+"""Row-streaming f16c8 weight gradient (csrc/conv_f16c8_wgrad_rows.hip; reference call site: the autograd weight
+gradient of nn.Conv2d 3x3, eo_vae/models/modules/layers.py:64-66, 81-83) against
+  * the fp32 weight gradient computed by torch on the CPU from the same GroupNorm+SiLU output,
+  * the tile kernel it replaces (same arithmetic per product, other summation order),
+on shapes that exercise every branch of the walk: several strips per image, row segments (few strips for the blocks of
+a slab), units that do not divide evenly among the blocks, one-row segments' halo rows, several ci / co slabs."""
+import pytest
+import torch
+
+from test_gpu_kernels import hashed, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # n, cin, cout, h, w
+    (2, 64, 128, 32, 32),     # one strip per image, segments of 8 rows
+    (3, 128, 128, 24, 64),    # 6 strips, 24 rows: segments of 12 rows, units % blocks != 0
+    (1, 192, 256, 40, 96),    # 3 ci slabs x 2 co slabs, H not a power of two
+    (2, 512, 128, 16, 32),    # 8 ci slabs: few blocks per slab
+    (16, 64, 128, 8, 32),     # short strips: 8 rows + 2 halo stages each
+    (1, 64, 128, 9, 32),      # odd H: a single segment
+]
+
+
+def _case(n, cin, cout, h, w):
+    from eo_vae_amd import ops
+    x = hashed((n, cin, h, w), 311, 1.0).cuda()
+    wt = hashed((cout, cin, 3, 3), 312, 1.0 / (cin * 9) ** 0.5).cuda()
+    b = hashed((cout,), 313, 0.1).cuda()
+    gy = hashed((n, cout, h, w), 314, 1e-3).cuda()
+    g = (1.0 + hashed((cin,), 315, 0.2)).cuda()
+    be = hashed((cin,), 316, 0.2).cuda()
+    return ops, x, wt, b, gy, g, be
+
+
+def _run(ops, x, wt, b, gy, g, be):
+    wg, bg = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    inp = ops.group_norm_silu(x, g, be, 32, 1e-6, True, True)
+    ops.conv2d(inp, wg, bg).backward(gy)
+    torch.cuda.synchronize()
+    return wg.grad.clone(), bg.grad.clone()
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', SHAPES)
+def test_rows_weight_gradient(n, cin, cout, h, w):
+    from eo_vae_amd import lib as L
+    lib = L.load()
+    ops, x, wt, b, gy, g, be = _case(n, cin, cout, h, w)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = lib.eovae_get_option(b'c8_wgrad_rows')
+    try:
+        assert ops.WGRAD_DIRECT, 'the row-streaming kernel serves the partial-tile path'
+        L.check(lib.eovae_set_option(b'c8_wgrad_rows', 1), 'set_option')
+        d1, b1 = _run(ops, x, wt, b, gy, g, be)
+        d2, _ = _run(ops, x, wt, b, gy, g, be)
+        L.check(lib.eovae_set_option(b'c8_wgrad_rows', 0), 'set_option')
+        t1, bt = _run(ops, x, wt, b, gy, g, be)
+        assert torch.equal(d1, d2)                      # fixed summation order: bit-reproducible
+        # fp32 reference on the CPU: the weight gradient of a plain convolution of the GroupNorm + SiLU output
+        xc = x.cpu().double()
+        act = torch.nn.functional.silu(torch.nn.functional.group_norm(xc, 32, g.cpu().double(), be.cpu().double(), 1e-6))
+        wref = wt.cpu().double().requires_grad_(True)
+        torch.nn.functional.conv2d(act, wref, None, padding=1).backward(gy.cpu().double())
+        e_ref, e_tile = rel_err(d1.cpu().double(), wref.grad), rel_err(d1, t1)
+        print(f'rows vs fp64 {e_ref:.2e}, tile kernel vs fp64 {rel_err(t1.cpu().double(), wref.grad):.2e}, rows vs tile {e_tile:.2e}')
+        assert e_ref < 5e-5 and e_tile < 2e-6      # f16c8 arithmetic: ~2e-5 per tensor in either kernel
+        assert rel_err(b1, bt) < 2e-6 and rel_err(b1.cpu().double(), gy.cpu().double().sum((0, 2, 3))) < 1e-5
+    finally:
+        lib.eovae_set_option(b'c8_wgrad_rows', keep)
+        ops.CONV_PRECISION = old
+
+
+def test_rows_kernel_is_the_default_and_switchable():
+    from eo_vae_amd import lib as L
+    lib = L.load()
+    assert lib.eovae_get_option(b'c8_wgrad_rows') == 1
+    assert lib.eovae_set_option(b'no_such_option', 1) != 0 and b'unknown option' in lib.eovae_last_error()
