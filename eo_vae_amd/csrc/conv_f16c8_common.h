@@ -40,7 +40,6 @@ struct WgCArgs {
   int xpacked;              // x = f16c8 operand records (GroupNorm-apply)
   float* part;              // plain layers: per-block partial sums [slab][split][9][128][64] instead of atomics into dwp (or null)
   int nseg, units;          // conv_f16c8_wgrad_rows.hip: row segments per strip, units (image x strip x segment) of the walk
-  unsigned magic_nseg, magic_tx;   // floor(2^32 / d) + 1 for d = nseg, tiles_x: division by multiply-high
 };
 
 namespace {

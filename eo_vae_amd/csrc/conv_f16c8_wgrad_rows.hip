@@ -20,14 +20,22 @@
 //   thread and stage) and read as the MFMA A operand by plain ds_read_b128 -- conflict-free with an odd 16-byte row pitch;
 //   only X, whose window moves with kx, needs the transposing reads.
 //   X arrives as GroupNorm operand records and goes global -> LDS by LDS-DMA (two buffer_load ... lds per wave and
-//   stage, 34 live lanes each: the f16 halves and the fp8 halves of one channel octet's 34 pixels; off-image pixels and rows are
-//   offsets beyond the descriptor's range, which the hardware fills with zeros): no registers, no VALU, no ds_write.
-//   Per wave and stage: ~40 VALU, 4 vector-memory and 31 LDS instructions for 27 MFMAs (tile kernel: ~135 / 10 / 62).
+//   stage, 34 live lanes each: the f16 halves and the fp8 halves of one channel octet's 34 pixels; off-image pixels are
+//   offsets beyond the descriptor's range, off-image rows a descriptor of zero records: the hardware fills in zeros): no
+//   registers, no VALU, no ds_write.
 //
-// LDS (118 KiB): three dY slots {f16 [128 co][80 B] | dyl' [128][48 B] | dyh' [128][48 B]} and three X slots
+// A stage is paced by instruction ISSUE as much as by the matrix pipes (timing-only ablations, profiles/r04g: without the
+// MFMAs the first build still took 0.65-0.74 of its time: ~240 instructions per wave and stage, 120 of them on the CU's
+// one scalar unit).  So the stage body carries nothing it can avoid: the walk is INCREMENTAL (a row step is two scalar
+// adds; descriptors' bases and the per-lane DMA offset change only when a unit opens, in a rarely taken branch), the MFMAs
+// are volatile asm statements in a fixed order with the other work placed between them by hand, the first MFMAs of a
+// stage run on operands that are in registers when the barrier opens.
+//
+// LDS (135 KiB): three dY slots {f16 [128 co][80 B] | dyl' [128][48 B] | dyh' [128][48 B]} and four X slots
 // {f16 planes [8 octets][34 px][16 B], pitch 1088 = 64 (mod 256) | fp8 planes [8 octets][34 px][xl' x 8 | xh' x 8] at
-// offsets = {0, 136, 8, 128} (mod 256) per ci-tile}: every fragment read of a 32-lane group covers 64 distinct banks.
-// The stage loop is unrolled by six so that slot, ring and register-set indices are compile-time.
+// offsets = {0, 136, 8, 128} (mod 256) per ci-tile}: every fragment read of a 32-lane group covers 64 distinct banks, and
+// the dY stores of a 16-lane group (rows co, co + 4, co + 2, co + 6) cover 32.
+// The stage loop is unrolled by twelve so that slot, ring and register-set indices are compile-time.
 //
 // Restrictions (else the tile kernel runs): plain form (subpix 0, mode NORMAL), record input, partial-tile output,
 // Cout % 128 == 0, Cin % 64 == 0, Wout % 32 == 0.
@@ -37,6 +45,13 @@
 
 #include "conv_f16c8_common.h"
 
+#ifndef EOVAE_ROWS_DBG
+#define EOVAE_ROWS_DBG 0   // bisection switches: 1 linear dY row map, 2 zeroed `old` operands of the fp8 conversions
+#endif
+#ifndef EOVAE_ROWS_ABL
+#define EOVAE_ROWS_ABL 0   // timing-only experiments (WRONG results): 1 no dY conversion, 2 no requests (loads, DMAs, cursor), 4 no barrier, 8 no MFMAs
+#endif
+
 namespace {
 
 constexpr int P16 = 80, P8 = 48;             // dY row pitches (bytes): 64 + 16, 32 + 16 -- odd multiples of 16
@@ -44,15 +59,13 @@ constexpr int DY16 = 128 * P16;              // f16 image of one dY row
 constexpr int DY8 = 128 * P8;                // one fp8 image
 constexpr int DYSLOT = DY16 + 2 * DY8;       // 22,528
 // Every LDS-DMA instruction deposits 64 lanes x 16 B = 1 KiB (lanes 34..63 carry an out-of-range offset and deposit
-// zeros): each octet's plane owns a 1 KiB window, so the instruction needs no EXEC mask -- and the request block no
-// branch (behind a branch the compiler sinks the stage's first MFMAs below the whole block).
+// zeros): each octet's plane owns a 1 KiB window, so the instruction needs no EXEC mask and the request block no branch.
 constexpr int XP16 = 1088;                   // f16 plane pitch per octet: 1 KiB window + 64 (= 64 mod 256)
 constexpr int X16 = 8 * XP16;                // 8,704
 constexpr int X8T = 4480;                    // fp8 planes of one ci-tile (4 octets, 1 KiB windows at the offsets of x8off())
 constexpr int XSLOT = X16 + 2 * X8T;         // 17,664
 constexpr int NRING = 3;
 
-static_assert(true, "");
 // windows of 1 KiB at {0, 136, 8, 128} (mod 256), at least 1 KiB apart
 __device__ __forceinline__ constexpr int x8off(int o) { return o == 0 ? 0 : (o == 1 ? 1160 : (o == 2 ? 2312 : 3456)); }
 
@@ -84,9 +97,11 @@ __device__ __forceinline__ i32x8 rtr8(const unsigned char* p) {   // 4 x 8 pixel
 // later, by another MFMA; (ii) A / B operands come from LDS reads (s_waitcnt by the compiler, which tracks the
 // registers); (iii) the epilogue's reads of the accumulators sit behind explicit s_nops.
 __device__ __forceinline__ void mfma16(f32x16& c, const f16x8& a, const f16x8& b) {
+  if (EOVAE_ROWS_ABL & 8) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return; }
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma8(f32x16& c, const i32x8& a, const i32x8& b, int sa, int sb) {
+  if (EOVAE_ROWS_ABL & 8) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return; }
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:1 blgp:1"
                : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
@@ -102,19 +117,15 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-// one stage of the walk: X row R of strip (n, x0) against dY rows R + 1, R, R - 1 of the unit's rows [r0, r1)
-struct RowStage {
-  int n, x0, R, r0, r1;
-  int live;   // 0: padding stage behind the block's last unit (all operands zero)
-};
-
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char dys[NRING * DYSLOT];
-  // THREE arrays for the LDS-DMA targets: with one array and a computed slot offset the compiler cannot tell a DMA write
-  // from the fragment reads of another slot and drains vmcnt(0) in front of every read (conv_f16c8_wgrad_w4.hip)
+  // FOUR arrays for the LDS-DMA targets (X row s + 3 is requested in stage s; row s + 1 is already read at the end of
+  // stage s): with one array and a computed slot offset the compiler cannot tell a DMA write from the fragment reads of
+  // another slot and drains vmcnt(0) in front of every read (conv_f16c8_wgrad_w4.hip)
   __shared__ __attribute__((aligned(16))) unsigned char xs0[XSLOT];
   __shared__ __attribute__((aligned(16))) unsigned char xs1[XSLOT];
   __shared__ __attribute__((aligned(16))) unsigned char xs2[XSLOT];
+  __shared__ __attribute__((aligned(16))) unsigned char xs3[XSLOT];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       ysub = b / nslab;
     }
   }
-  const int cib = slab % a.ncib, cob = slab / a.ncib;
+  const int cib = uni(slab % a.ncib), cob = uni(slab / a.ncib);
   const int H = a.Hout, W = a.Wout;
   const unsigned plane = (unsigned)(H * W);
 
@@ -148,111 +159,127 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   }
   const int sc_a = 127 - 12, sc_b = 127;   // E8M0: both K blocks carry one operand scaled by 2^12
 
-  // ---- the walk: units u = ysub, ysub + split, ... ; unit = (image n, strip tx, row segment seg)
-  const int segrows = __builtin_amdgcn_readfirstlane(H / a.nseg);
-  int unit = __builtin_amdgcn_readfirstlane(ysub - a.split);
-  RowStage cur;
-  cur.n = 0; cur.x0 = 0; cur.R = 0; cur.r0 = 0; cur.r1 = -1; cur.live = 1;   // R > r1: the first next() opens a unit
-  // BRANCH-FREE (selects, divisions by multiply-high with host-made reciprocals): the cursor steps inside the MFMA
-  // sequence, and behind a branch the compiler sinks the MFMAs in front of it into the join block.  Every field goes
-  // through readfirstlane, so that a buffer descriptor built from it is not loaded inside a waterfall loop.
-  auto next = [&]() __attribute__((always_inline)) {
-    const int open = (cur.R >= cur.r1) & cur.live;
-    unit = uni(unit + (open ? a.split : 0));
-    const int dead = open & (unit >= a.units);
-    const unsigned u = (unsigned)(dead ? 0 : unit);
-    const unsigned t = a.nseg == 1 ? u : __umulhi(u, a.magic_nseg), seg = u - t * (unsigned)a.nseg;       // (the reciprocal
-    const unsigned n = a.tiles_x == 1 ? t : __umulhi(t, a.magic_tx), tx = t - n * (unsigned)a.tiles_x;   // of 1 is 2^32)
-    const int r0n = (int)seg * segrows;
-    cur.live = uni(cur.live & !dead);
-    cur.x0 = uni(open ? (int)tx * 32 : cur.x0);
-    cur.n = uni(open ? (int)n : cur.n);
-    cur.R = uni(open ? r0n - 1 : cur.R + 1);
-    cur.r0 = uni(open ? r0n : cur.r0);
-    cur.r1 = uni(open ? r0n + segrows : cur.r1);
+  // ---- the walk: units u = ysub, ysub + split, ... ; unit = (image n, strip tx, row segment seg) covers output rows
+  // [r0, r1); its stages are the X rows R = r0 - 1 .. r1 (dY rows outside [r0, r1) and X rows outside the image: zeros).
+  // The cursor `c` is the stage whose X row is requested next.  A row step is two scalar adds; the descriptors' bases and
+  // the per-lane DMA offset change only when a unit opens.
+  const int segrows = uni(H / a.nseg);
+  const unsigned OOR = 0x80000000u;
+  const unsigned dyspan = (unsigned)a.Cout * plane * 4u, xspan = 8u * plane * 32u;
+  struct Cursor {
+    int R, r0, r1, live;
+    unsigned xsoff, dsoff;     // byte offsets of X row R / of dY row R + 1 at the strip's first column (scalar offsets)
+    const char* xbase;         // records of image n, channel octets 8 cib .. 8 cib + 7
+    const float* dbase;        // dY of image n
+  } c;
+  c.R = 0; c.r0 = 0; c.r1 = -1; c.live = 1; c.xsoff = 0; c.dsoff = 0;
+  c.xbase = reinterpret_cast<const char*>(a.x); c.dbase = a.dy;
+  int unit = uni(ysub - a.split);
+  unsigned vx = OOR;           // lane's DMA offset inside the descriptor: octet `wave`, pixel column x0 - 1 + lane (or OOR)
+  auto step = [&]() __attribute__((always_inline)) {
+    if (c.live && c.R >= c.r1) {   // wave-uniform, taken once per unit
+      asm volatile("" ::: "memory");   // a real branch: if-converted, the cursor's scalars turn into vector selects
+      unit = uni(unit + a.split);
+      if (unit >= a.units) {
+        c.live = 0;
+      } else {
+        const int seg = unit % a.nseg, t = unit / a.nseg;
+        const int x0 = uni((t % a.tiles_x) * 32), n = uni(t / a.tiles_x);
+        c.r0 = uni(seg * segrows);
+        c.r1 = c.r0 + segrows;
+        c.R = c.r0 - 1;
+        c.xsoff = (unsigned)uni((c.R * W) * 32);
+        c.dsoff = (unsigned)uni((c.r0 * W + x0) * 4);
+        c.xbase = uni_ptr(reinterpret_cast<const char*>(a.x) + ((size_t)n * (a.Cin / 8) + (size_t)cib * 8) * plane * 32);
+        c.dbase = uni_ptr(a.dy + (size_t)n * a.Cout * plane);
+        const unsigned ln = threadIdx.x & 63u;
+        const int px = x0 - 1 + (int)ln;
+        vx = (ln < 34u && (unsigned)px < (unsigned)W) ? ((unsigned)wave * plane + (unsigned)px) * 32u : OOR;
+      }
+    } else {
+      ++c.R;
+      c.xsoff += (unsigned)(W * 32);
+      c.dsoff += (unsigned)(W * 4);
+    }
   };
   int nst;   // stages of this block
   {
     const int mine = ysub < a.units ? (a.units - ysub + a.split - 1) / a.split : 0;
-    nst = mine * (segrows + 2);
+    nst = uni(mine * (segrows + 2));
   }
 
-  // ---- dY staging: thread -> (co = tid >> 2, pixels 8 (tid & 3) .. + 7): two 16-byte loads, 28 conversions, three stores.
-  // The loads are UNCONDITIONAL: a row outside the unit is an offset beyond the descriptor's range and comes back as
+  // ---- dY staging: thread -> (row co, pixels 8 q .. 8 q + 7): two 16-byte loads, ~30 conversions, three stores.  The rows
+  // of 16 consecutive lanes are co, co + 4, co + 2, co + 6 (two per 8-lane group): with the 80- / 48-byte pitches their
+  // 64- / 32-byte pieces fall into disjoint banks, so the stores are conflict-free too.
+  // The loads are UNCONDITIONAL: a row outside the unit is read through a descriptor of zero records and comes back as
   // zeros (a branch around the loads would make the registers phi nodes behind an s_waitcnt vmcnt(0)).  Two register
-  // sets: the row of stage s + 2 is requested at the top of stage s, the row of stage s + 1 is converted piecewise
-  // between the MFMAs of stage s.
-  const int dco = tid >> 2, dq = tid & 3;
+  // sets: the row of stage s + 2 is requested in stage s, the row of stage s + 1 is converted between the MFMAs of stage s.
+  const int dq = tid & 3;
+  const int dco = (EOVAE_ROWS_DBG & 1) ? (tid >> 2) : 8 * (tid >> 5) + ((tid >> 4) & 1) + (((tid >> 2) & 1) << 2) + (((tid >> 3) & 1) << 1);
   const unsigned dvoff = ((unsigned)(cob * 128 + dco) * plane + 8u * (unsigned)dq) * 4u;
-  const unsigned dyspan = (unsigned)a.Cout * plane * 4u;
   f32x4 dr[2][2];
   float dbs = 0.f;
-  auto load_dy = [&](const RowStage& s, auto pc) __attribute__((always_inline)) {
+  const bool do_db = a.db != nullptr && cib == 0;
+  struct { const float* base; unsigned soff; int ok; } sv;   // the dY row of the cursor's stage, requested a stage later
+  sv.base = a.dy; sv.soff = 0; sv.ok = 0;
+  auto save_dy = [&]() __attribute__((always_inline)) {
+    sv.base = c.dbase;
+    sv.soff = c.dsoff;
+    sv.ok = c.live & (c.R + 1 >= c.r0) & (c.R + 1 < c.r1);
+  };
+  auto request_dy = [&](auto pc) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
-    const int y = s.R + 1;
-    const bool ok = uni(s.live && y >= s.r0 && y < s.r1) != 0;
+    const unsigned so = (EOVAE_ROWS_DBG & 8) ? (unsigned)uni((int)sv.soff) : sv.soff;
+    const unsigned nr = (EOVAE_ROWS_DBG & 8) ? (unsigned)uni(sv.ok ? (int)dyspan : 0) : (sv.ok ? dyspan : 0u);
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-        uni_ptr(const_cast<float*>(a.dy) + (size_t)(ok ? s.n : 0) * a.Cout * plane), 0, dyspan, 0x00020000);
-    const int so = uni(ok ? (y * W + s.x0) * 4 : 0);
-    const unsigned vo = ok ? dvoff : 0x80000000u;
-    dr[P][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, vo, so, 0));
-    dr[P][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, vo + 16, so, 0));
+        (EOVAE_ROWS_DBG & 8) ? uni_ptr(const_cast<float*>(sv.base)) : const_cast<float*>(sv.base), 0, nr, 0x00020000);
+    dr[P][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, dvoff, so, 0));
+    dr[P][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, dvoff + 16, so, 0));
   };
   const int dw16 = dco * P16 + dq * 16, dw8 = DY16 + dco * P8 + dq * 8;
-  // conversion of one register set in three pieces placed between MFMA triples: pixels 0-3 | pixels 4-7 | stores (every
-  // intermediate is dead at the end of its piece: only the 8 result registers live across MFMAs)
-  i32x4 chi;
-  i32x2 cl8, ch8;
+  // conversion of one register set in two pieces placed between MFMA triples: pixels 0-3 | pixels 4-7, each stored at once
+  // (8 + 4 + 4 bytes): nothing of a piece lives across an MFMA
   auto conv_piece = [&](auto pc, auto piece, unsigned char* slot) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value, I = decltype(piece)::value;
-    if constexpr (I < 2) {
-      const f32x4 d = dr[P][I];
-      float v[4], lo[4];
+    const f32x4 d = dr[P][I];
+    float v[4], lo[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = d[j] * dys_scale;
+    for (int j = 0; j < 4; ++j) v[j] = d[j] * dys_scale;
+    if (do_db) {   // uniform
       float t0 = d[0] + d[1], t1 = d[2] + d[3];
       asm volatile("" : "+v"(t0), "+v"(t1));   // scalar adds: packed f32 VALU is slow beside MFMAs
       dbs += t0 + t1;
-#pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        int hp;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[j]), "v"(v[j + 1]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hp), "v"(v[j]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hp), "v"(v[j + 1]));
-        chi[2 * I + (j >> 1)] = hp;
-      }
-      s16x2 lv = {0, 0};
-      lv = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lv, lo[0], lo[1], 0x1p-12f, false);
-      lv = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lv, lo[2], lo[3], 0x1p-12f, true);
-      cl8[I] = __builtin_bit_cast(int, lv);
-      int hv = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
-      hv = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], hv, true);
-      ch8[I] = hv;
-    } else {
-      *reinterpret_cast<i32x4*>(slot + dw16) = chi;
-      *reinterpret_cast<i32x2*>(slot + dw8) = cl8;          // image 0: dyl'
-      *reinterpret_cast<i32x2*>(slot + dw8 + DY8) = ch8;    // image 1: dyh'
     }
+    i32x2 hi;
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      int hp;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[j]), "v"(v[j + 1]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hp), "v"(v[j]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hp), "v"(v[j + 1]));
+      hi[j >> 1] = hp;
+    }
+    // (the `old` operands are don't-cares: both halves of each result are written)
+    s16x2 lv = __builtin_bit_cast(s16x2, (EOVAE_ROWS_DBG & 2) ? 0.f : lo[0]);
+    lv = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lv, lo[0], lo[1], 0x1p-12f, false);
+    lv = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lv, lo[2], lo[3], 0x1p-12f, true);
+    int hv = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], (EOVAE_ROWS_DBG & 2) ? 0 : __builtin_bit_cast(int, v[0]), false);
+    hv = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], hv, true);
+    *reinterpret_cast<i32x2*>(slot + dw16 + 8 * I) = hi;
+    *reinterpret_cast<int*>(slot + dw8 + 4 * I) = __builtin_bit_cast(int, lv);   // image 0: dyl'
+    *reinterpret_cast<int*>(slot + dw8 + DY8 + 4 * I) = hv;                     // image 1: dyh'
   };
 
   // ---- X by LDS-DMA: wave w moves channel octet w of the slab (ci-tile w >> 2, octet w & 3 of it)
-  const unsigned OOR = 0x80000000u;
-  const unsigned xspan = 8u * plane * 32u;
   const int x16dst = uni(wave * XP16), x8dst = uni(X16 + (wave >> 2) * X8T + x8off(wave & 3));
-  auto dma_x = [&](unsigned char* xslot, const RowStage& s) __attribute__((always_inline)) {
-    unsigned ln = threadIdx.x & 63u;
-    asm volatile("" : "+v"(ln));   // recomputed at its use, not carried in a register across the MFMA phases
-    const int px = s.x0 - 1 + (int)ln;
-    const bool rowok = uni(s.live && (unsigned)s.R < (unsigned)H) != 0;
-    const bool ok = rowok && ln < 34u && (unsigned)px < (unsigned)W;
-    const unsigned v = ok ? ((unsigned)wave * plane + (unsigned)(uni(s.R * W) + px)) * 32u : OOR;
-    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-        uni_ptr(const_cast<char*>(reinterpret_cast<const char*>(a.x)) +
-                ((size_t)(rowok ? s.n : 0) * (a.Cin / 8) + (size_t)cib * 8) * plane * 32),
-        0, xspan, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x16dst), 16, (int)v, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x8dst), 16,
-                                             (int)(ok ? v + 16u : OOR), 0, 0, 0);
+  auto request_x = [&](unsigned char* xslot) __attribute__((always_inline)) {
+    const int ok = c.live & ((unsigned)c.R < (unsigned)H);
+    const int so = (int)c.xsoff;
+    const __amdgpu_buffer_rsrc_t srd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xbase), 0, ok ? xspan : 0u, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x16dst), 16, (int)vx, so, 0, 0);
+    // (the records' second halves through the SCALAR offset: an LDS-DMA's immediate offset also moves its LDS address)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x8dst), 16, (int)vx, so + 16, 0, 0);
   };
 
   // ---- fragment addresses (per-lane constants; slot, tap shift and k-step are immediates)
@@ -280,43 +307,51 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   }
 
   auto xslot_of = [&](auto kc) __attribute__((always_inline)) -> unsigned char* {
-    constexpr int k = decltype(kc)::value % 3;
+    constexpr int k = decltype(kc)::value % 4;
     if constexpr (k == 0) return xs0;
     else if constexpr (k == 1) return xs1;
-    else return xs2;
+    else if constexpr (k == 2) return xs2;
+    else return xs3;
   };
 
-  // ---- prologue: X(0), X(1) in flight, dY(0) committed, dY(1) in registers; `cur` = the stage requested next
+  // ---- prologue: X(0..2) in flight, dY(0) committed, dY(1) in registers, dY(2) noted; the cursor ends at stage 3
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
-  using C2 = std::integral_constant<int, 2>;
-  next();
-  dma_x(xs0, cur);
-  load_dy(cur, C0{});
-  next();
-  dma_x(xs1, cur);
-  load_dy(cur, C1{});
+  step();
+  request_x(xs0);
+  save_dy();
+  request_dy(C0{});
+  step();
+  request_x(xs1);
+  save_dy();
+  request_dy(C1{});
   conv_piece(C0{}, C0{}, dys);
   conv_piece(C0{}, C1{}, dys);
-  conv_piece(C0{}, C2{}, dys);
-  next();            // stage 2
+  step();
+  request_x(xs2);
+  save_dy();
+  step();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // the fp8 B fragment of a stage's first MFMAs is read at the end of the stage before it (X rows land two stages
+  // ahead): behind the barrier a stage starts multiplying at once, on operands that are all in registers
+  i32x8 b8 = rtr8(xs0 + b8off);
 
-  // stage s: K = s mod 3 (LDS slots, register ring), P = s mod 2 (dY register set that receives row s + 2; row s + 1 sits in the other)
-  auto body = [&](auto kc, auto pc) __attribute__((always_inline)) {
-    constexpr int K = decltype(kc)::value, P = decltype(pc)::value;
-    constexpr int KD = (K + 1) % 3, KX = (K + 2) % 3;
+  // stage s: S = s mod 12; K = s mod 3 (dY slots, register ring), P = s mod 2 (dY register set that receives row s + 2; row
+  // s + 1 sits in the other), Q = s mod 4 (X slot)
+  auto body = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value, K = S % 3, P = S % 2, Q = S % 4;
+    constexpr int KD = (K + 1) % 3;
+    using PC = std::integral_constant<int, P>;
     using PN = std::integral_constant<int, P ^ 1>;
     const unsigned char* dsl = dys + K * DYSLOT;
     unsigned char* dnx = dys + KD * DYSLOT;
-    const unsigned char* xsl = xslot_of(kc);
-    // A stage opens with every wave of the CU behind the same barrier and the matrix pipes idle: nothing but the first
-    // triple's operands is requested in front of it, and that triple multiplies the two OLD dY rows (registers) first.
-    // The requests of X row s + 2 and dY row s + 2 (address arithmetic, two loads, two LDS-DMAs, the cursor step: ~90
-    // scalar / vector instructions) ride between the MFMAs of kx = 0; the conversion of dY row s + 1 (requested a stage
-    // ago) between the triples of kx = 1.
-    i32x8 b8 = rtr8(xsl + b8off);
+    const unsigned char* xsl = xslot_of(std::integral_constant<int, Q>{});
+    // A stage opens with every wave of the CU behind the same barrier and the matrix pipes idle.  Its first two MFMAs
+    // multiply the two OLD dY rows (register ring) with the B fragment read before the barrier; the new row's A
+    // fragments are requested first thing and are needed by the third MFMA.  The requests of dY row s + 2 and X row
+    // s + 3 and the cursor step ride between the MFMAs of kx = 0, the conversion of dY row s + 1 (requested a stage ago)
+    // between the triples of kx = 1.
     {
       const i32x4 l = *reinterpret_cast<const i32x4*>(dsl + a8off), u = *reinterpret_cast<const i32x4*>(dsl + a8off + 16);
       A8[K] = (i32x8)__builtin_shufflevector(l, u, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -328,53 +363,76 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     for (int kx = 0; kx < 3; ++kx) {
       const f16x8 b0 = rtr16(xsl + b16off + kx * 16, xsl + b16off + (kx + 4) * 16);
       if (kx == 1) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // newer than dY(s + 1): X(s + 1), dY(s + 2), X(s + 2) -- two operations each
-        conv_piece(PN{}, C0{}, dnx);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3) -- two operations each
+        if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma8(acc[3 + kx], A8[R1], b8, sc_a, sc_b);
-      if (kx == 0) load_dy(cur, pc);
+      if (kx == 0) {
+        __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
+        if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
+      }
       mfma8(acc[6 + kx], A8[R2], b8, sc_a, sc_b);
-      if (kx == 0) dma_x(xslot_of(std::integral_constant<int, KX>{}), cur);
+      if (kx == 0 && !(EOVAE_ROWS_ABL & 2)) {
+        request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
+        save_dy();
+      }
       mfma8(acc[kx], A8[K], b8, sc_a, sc_b);
-      if (kx == 0) next();
+      if (kx == 0 && !(EOVAE_ROWS_ABL & 2)) step();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 b1 = rtr16(xsl + b16off + (kx + 16) * 16, xsl + b16off + (kx + 20) * 16);
-      if (kx == 1) conv_piece(PN{}, C1{}, dnx);
+      if (kx == 1 && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
       __builtin_amdgcn_sched_barrier(0);
       mfma16(acc[3 + kx], A16[R1][0], b0);
       mfma16(acc[6 + kx], A16[R2][0], b0);
       mfma16(acc[kx], A16[K][0], b0);
       __builtin_amdgcn_sched_barrier(0);
       if (kx < 2) b8 = rtr8(xsl + b8off + (kx + 1) * 16);
-      if (kx == 1) conv_piece(PN{}, C2{}, dnx);
+      else b8 = rtr8(xslot_of(std::integral_constant<int, (Q + 1) % 4>{}) + b8off);   // the next stage's first B fragment
       __builtin_amdgcn_sched_barrier(0);
       mfma16(acc[3 + kx], A16[R1][1], b1);
       mfma16(acc[6 + kx], A16[R2][1], b1);
       mfma16(acc[kx], A16[K][1], b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // X(s + 1) has landed when at most this stage's four operations are outstanding
+    // X(s + 2) has landed when at most this stage's four operations are outstanding
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __syncthreads();
+    if (!(EOVAE_ROWS_ABL & 4)) __syncthreads();
   };
 
-  {
-    int s = 0;
+  // ONE exit: with an exit behind every body (twelve exits) the compiler kept the cursor's scalars in vector registers and
+  // loaded every descriptor inside a waterfall loop.  The stages that pad the count to a multiple of twelve lie behind
+  // the block's last unit: zero operands.
 #pragma unroll 1
-    while (true) {
-      body(C0{}, C0{}); if (++s >= nst) break;
-      body(C1{}, C1{}); if (++s >= nst) break;
-      body(C2{}, C0{}); if (++s >= nst) break;
-      body(C0{}, C1{}); if (++s >= nst) break;
-      body(C1{}, C0{}); if (++s >= nst) break;
-      body(C2{}, C1{}); if (++s >= nst) break;
-    }
+  for (int s = 0; s < nst; s += 12) {
+    body(std::integral_constant<int, 0>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 1 >= nst) break;
+    body(std::integral_constant<int, 1>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 2 >= nst) break;
+    body(std::integral_constant<int, 2>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 3 >= nst) break;
+    body(std::integral_constant<int, 3>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 4 >= nst) break;
+    body(std::integral_constant<int, 4>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 5 >= nst) break;
+    body(std::integral_constant<int, 5>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 6 >= nst) break;
+    body(std::integral_constant<int, 6>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 7 >= nst) break;
+    body(std::integral_constant<int, 7>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 8 >= nst) break;
+    body(std::integral_constant<int, 8>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 9 >= nst) break;
+    body(std::integral_constant<int, 9>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 10 >= nst) break;
+    body(std::integral_constant<int, 10>{});
+    if ((EOVAE_ROWS_DBG & 4) && s + 11 >= nst) break;
+    body(std::integral_constant<int, 11>{});
   }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // requests of the two stages behind
-                                                                                     // the last one; the asm MFMAs' results
+  // requests of the stages behind the last one; the asm MFMAs' results are read below: well past their latency
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  if (a.db != nullptr && cib == 0) {   // lanes 4 co .. 4 co + 3 hold the same channel
+  if (do_db) {   // lanes 4 k .. 4 k + 3 hold the same channel
     float v = dbs;
     v += dpp_quad<0xB1>(v);
     v += dpp_quad<0x4E>(v);
@@ -395,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
 
 bool eovae_c8_wgrad_rows_eligible(const WgCArgs& a) {
   return eovae_opt(EOVAE_OPT_WGRAD_ROWS) != 0 && a.part && a.subpix == 0 && a.mode == MODE_NORMAL && a.xpacked && a.Cout % 128 == 0 &&
-         a.Cin % 64 == 0 && a.Wout % 32 == 0 && a.Hout >= 1 && !a.xamax && (long long)a.N * a.tiles_x * a.Hout < 65536 &&
+         a.Cin % 64 == 0 && a.Wout % 32 == 0 && a.Hout >= 1 && !a.xamax &&
          (long long)a.Hout * a.Wout * 32 * 8 < (1LL << 31) && (long long)a.Cout * a.Hout * a.Wout * 4 < (1LL << 32);
 }
 
@@ -406,9 +464,6 @@ void eovae_c8_wgrad_rows_launch(WgCArgs& a, hipStream_t st) {
   while (strips * nseg < a.split && a.Hout % (2 * nseg) == 0 && a.Hout / (2 * nseg) >= 8) nseg *= 2;
   a.nseg = nseg;
   a.units = strips * nseg;
-  // floor(u / d) = umulhi(u, floor(2^32 / d) + 1) for u < 2^16, d < 2^16 (units and strips are far below that)
-  a.magic_nseg = (unsigned)(0x100000000ull / (unsigned)nseg) + 1u;
-  a.magic_tx = (unsigned)(0x100000000ull / (unsigned)a.tiles_x) + 1u;
   if (a.split > a.units) a.split = a.units;
   a.xcd_remap = (a.ncib * a.ncob_ > 1 && a.split % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel, dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);

@@ -6,7 +6,7 @@ tag = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 dur = collections.defaultdict(list)
-KERNELS = ['conv3x3_f16c8_w4_kernel', 'conv3x3_f16c8_kernel', 'wgrad3x3_f16c8_w4_kernel', 'wgrad3x3_f16c8_kernel']
+KERNELS = ['conv3x3_f16c8_w4_kernel', 'conv3x3_f16c8_kernel', 'wgrad3x3_f16c8_w4_kernel', 'wgrad3x3_f16c8_rows_kernel', 'wgrad3x3_f16c8_kernel']
 for f in glob.glob(os.path.join(root, f'pmcsq3?_{tag}_*', '*', '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         k = next((k for k in KERNELS if k in r['Kernel_Name']), None)
