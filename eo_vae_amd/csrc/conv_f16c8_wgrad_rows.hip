@@ -48,6 +48,10 @@
 #ifndef EOVAE_ROWS_DBG
 #define EOVAE_ROWS_DBG 0   // bisection switches: 1 linear dY row map, 2 zeroed `old` operands of the fp8 conversions
 #endif
+#ifndef EOVAE_ROWS_ROLES
+#define EOVAE_ROWS_ROLES 0   // 1: waves 4-7 request / convert one kx later than waves 0-3 -- measured 3-5 % SLOWER (profiles/r04j_roles_ab.log:
+                             // a second copy of the 12-stage loop, 34 spilled registers); the two waves of a SIMD run in step
+#endif
 #ifndef EOVAE_ROWS_ABL
 #define EOVAE_ROWS_ABL 0   // timing-only experiments (WRONG results): 1 no dY conversion, 2 no requests (loads, DMAs, cursor), 4 no barrier, 8 no MFMAs
 #endif
@@ -339,8 +343,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
 
   // stage s: S = s mod 12; K = s mod 3 (dY slots, register ring), P = s mod 2 (dY register set that receives row s + 2; row
   // s + 1 sits in the other), Q = s mod 4 (X slot)
-  auto body = [&](auto sc) __attribute__((always_inline)) {
+  auto body = [&](auto sc, auto rolec) __attribute__((always_inline)) {
     constexpr int S = decltype(sc)::value, K = S % 3, P = S % 2, Q = S % 4;
+    // (EOVAE_ROWS_ROLES: the two waves of a SIMD place their non-MFMA work one kx apart)
+    constexpr int KREQ = decltype(rolec)::value, KCNV = KREQ + 1;
     constexpr int KD = (K + 1) % 3;
     using PC = std::integral_constant<int, P>;
     using PN = std::integral_constant<int, P ^ 1>;
@@ -362,26 +368,26 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const f16x8 b0 = rtr16(xsl + b16off + kx * 16, xsl + b16off + (kx + 4) * 16);
-      if (kx == 1) {
+      if (kx == KCNV) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3) -- two operations each
         if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma8(acc[3 + kx], A8[R1], b8, sc_a, sc_b);
-      if (kx == 0) {
+      if (kx == KREQ) {
         __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
         if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
       }
       mfma8(acc[6 + kx], A8[R2], b8, sc_a, sc_b);
-      if (kx == 0 && !(EOVAE_ROWS_ABL & 2)) {
+      if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) {
         request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
         save_dy();
       }
       mfma8(acc[kx], A8[K], b8, sc_a, sc_b);
-      if (kx == 0 && !(EOVAE_ROWS_ABL & 2)) step();
+      if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) step();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 b1 = rtr16(xsl + b16off + (kx + 16) * 16, xsl + b16off + (kx + 20) * 16);
-      if (kx == 1 && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
+      if (kx == KCNV && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
       __builtin_amdgcn_sched_barrier(0);
       mfma16(acc[3 + kx], A16[R1][0], b0);
       mfma16(acc[6 + kx], A16[R2][0], b0);
@@ -403,32 +409,24 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   // ONE exit: with an exit behind every body (twelve exits) the compiler kept the cursor's scalars in vector registers and
   // loaded every descriptor inside a waterfall loop.  The stages that pad the count to a multiple of twelve lie behind
   // the block's last unit: zero operands.
+  auto run = [&](auto rolec) __attribute__((always_inline)) {
 #pragma unroll 1
-  for (int s = 0; s < nst; s += 12) {
-    body(std::integral_constant<int, 0>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 1 >= nst) break;
-    body(std::integral_constant<int, 1>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 2 >= nst) break;
-    body(std::integral_constant<int, 2>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 3 >= nst) break;
-    body(std::integral_constant<int, 3>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 4 >= nst) break;
-    body(std::integral_constant<int, 4>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 5 >= nst) break;
-    body(std::integral_constant<int, 5>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 6 >= nst) break;
-    body(std::integral_constant<int, 6>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 7 >= nst) break;
-    body(std::integral_constant<int, 7>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 8 >= nst) break;
-    body(std::integral_constant<int, 8>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 9 >= nst) break;
-    body(std::integral_constant<int, 9>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 10 >= nst) break;
-    body(std::integral_constant<int, 10>{});
-    if ((EOVAE_ROWS_DBG & 4) && s + 11 >= nst) break;
-    body(std::integral_constant<int, 11>{});
-  }
+    for (int s = 0; s < nst; s += 12) {
+      body(std::integral_constant<int, 0>{}, rolec);
+      body(std::integral_constant<int, 1>{}, rolec);
+      body(std::integral_constant<int, 2>{}, rolec);
+      body(std::integral_constant<int, 3>{}, rolec);
+      body(std::integral_constant<int, 4>{}, rolec);
+      body(std::integral_constant<int, 5>{}, rolec);
+      body(std::integral_constant<int, 6>{}, rolec);
+      body(std::integral_constant<int, 7>{}, rolec);
+      body(std::integral_constant<int, 8>{}, rolec);
+      body(std::integral_constant<int, 9>{}, rolec);
+      body(std::integral_constant<int, 10>{}, rolec);
+      body(std::integral_constant<int, 11>{}, rolec);
+    }
+  };
+  if (EOVAE_ROWS_ROLES && wave >= 4) run(C1{}); else run(C0{});
   // requests of the stages behind the last one; the asm MFMAs' results are read below: well past their latency
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
