@@ -384,6 +384,8 @@ class EOFluxVAE(LightningModule):
 
         images, wvs = batch[self.image_key], batch['wvs']
         target = images
+        if images.is_cuda:
+            ops.raise_on_gn_backward_timeouts()   # a time-out of an earlier step's one-pass GroupNorm backward
         self._prepack_weights()     # every plain 3x3 layer's f16c8 packs from two launches (ops.WeightPrepack)
         try:
             scale_bins = [0.375, 0.5, 0.75]

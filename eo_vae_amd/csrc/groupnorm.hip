@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <unistd.h>
 #include <chrono>
+#include <mutex>
 #include <random>
 
 namespace {
@@ -698,7 +699,8 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
                                                                     unsigned* __restrict__ amax_bits,
                                                                     const unsigned long long* __restrict__ err,
                                                                     unsigned long long token, int N, int C, int HW, int cpg,
-                                                                    unsigned* __restrict__ ticket) {
+                                                                    unsigned* __restrict__ ticket,
+                                                                    unsigned long long* __restrict__ sticky) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave;
   // the launch's token (host value + device epoch, as gnf_token); the LAST block to get here resets the ticket counter
@@ -725,6 +727,9 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
     a2 = wave_sum_d(a2);
     if (lane == 0) {
       const bool bad = *err == token;
+      // a time-out also lands in a host-visible word that survives the call (eovae_gn_bwd_timeouts): the NaNs below poison
+      // this step's gradients, the host raises at its next check instead of training on
+      if (bad && c == 0) *reinterpret_cast<volatile unsigned long long*>(sticky) = token | 1ull;
       dbeta[c] = bad ? __builtin_nanf("") : (float)a1;
       dgamma[c] = bad ? __builtin_nanf("") : (float)a2;
     }
@@ -742,6 +747,16 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
     }
   }
 }
+
+// host-side state of the one-pass backward's hand-off protocol (see eovae_gn_silu_bwd)
+constexpr int GN_MAX_DEV = 64, GN_MAX_CTL = 256;
+struct GnCtl { int dev; hipStream_t st; unsigned* block; };
+std::mutex g_gn_mu;
+unsigned long long g_gn_nonce = 0, g_gn_calls = 0;
+GnCtl g_gn_ctl[GN_MAX_CTL];
+int g_gn_nctl = 0;
+unsigned long long* g_gn_sticky_host[GN_MAX_DEV] = {nullptr};
+unsigned long long* g_gn_sticky_dev[GN_MAX_DEV] = {nullptr};
 
 // plan of the fused backward for one shape: V float4 per thread, team size T; T = 0 when the shape is not eligible
 struct GnBwdPlan { int V, T, nteams, grid, pipe; };
@@ -892,6 +907,20 @@ int eovae_gn_bwd_fused(int on) {
   if (on == 0 || on == 1 || on == 2) g_gn_bwd_fused = on;
   return g_gn_bwd_fused;
 }
+// Time-outs of the one-pass backward's team hand-off on the current device since the last clear: 0 = none, else the
+// token of the latest one.  Reads host memory the kernels write through: meaningful for launches the caller has
+// synchronised with; costs nothing, so a trainer checks it once per step.  clear != 0 resets the word.
+unsigned long long eovae_gn_bwd_timeouts(int clear) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEV) return 0ull;
+  std::lock_guard<std::mutex> lock(g_gn_mu);
+  unsigned long long* h = g_gn_sticky_host[dev];
+  if (!h) return 0ull;
+  const unsigned long long v = *reinterpret_cast<volatile unsigned long long*>(h);
+  if (clear) *reinterpret_cast<volatile unsigned long long*>(h) = 0ull;
+  return v;
+}
+
 // 1 when eovae_gn_silu_bwd would take the fused kernel for this shape
 int eovae_gn_bwd_fused_eligible(int N, int C, int HW, int G) {
   if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
@@ -918,34 +947,64 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
     // concurrent) process filled with granules of the very same call sequence, so a plain call counter is not enough
     // (seen: two ranks sharing one GPU accepted each other's stale granules now and then).  64 random-looking bits:
     // splitmix64 of (process nonce + call number).
-    static unsigned long long nonce = 0, calls = 0;
-    if (nonce == 0) {
-      std::random_device rd;
-      nonce = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ ((unsigned long long)getpid() << 17) ^
-              (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
-      nonce |= 1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEV) {
+      eovae_set_error("gn_silu_bwd: device index");
+      return EOVAE_ERR_LAUNCH;
     }
-    unsigned long long z = nonce + 0x9E3779B97F4A7C15ull * ++calls;
+    // Process-wide state of the hand-off protocol, all behind one mutex (ctypes releases the GIL: two host threads may be
+    // in here at once): the token sequence, and one control block (ticket counter + epoch) per (device, STREAM) -- two
+    // backward passes on different streams of one device must not draw tickets from the same counter (their members
+    // would interleave and the teams time out).  A block is zeroed on the stream that owns it, i.e. ordered in front of
+    // its first use; the time-out word is host memory mapped into the device, one per device.
+    unsigned long long z;
+    unsigned* ticket_block = nullptr;
+    unsigned long long* sticky_dev = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(g_gn_mu);
+      if (g_gn_nonce == 0) {
+        std::random_device rd;
+        g_gn_nonce = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ ((unsigned long long)getpid() << 17) ^
+                     (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+        g_gn_nonce |= 1;
+      }
+      z = g_gn_nonce + 0x9E3779B97F4A7C15ull * ++g_gn_calls;
+      if (!g_gn_sticky_host[dev]) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+          eovae_set_error("gn_silu_bwd: cannot allocate the time-out word");
+          return EOVAE_ERR_LAUNCH;
+        }
+        *reinterpret_cast<volatile unsigned long long*>(h) = 0ull;
+        g_gn_sticky_host[dev] = reinterpret_cast<unsigned long long*>(h);
+        g_gn_sticky_dev[dev] = reinterpret_cast<unsigned long long*>(d);
+      }
+      sticky_dev = g_gn_sticky_dev[dev];
+      for (int i = 0; i < g_gn_nctl; ++i)
+        if (g_gn_ctl[i].dev == dev && g_gn_ctl[i].st == st) ticket_block = g_gn_ctl[i].block;
+      if (!ticket_block) {
+        if (g_gn_nctl >= GN_MAX_CTL) {
+          eovae_set_error("gn_silu_bwd: more than %d (device, stream) pairs use the one-pass backward", GN_MAX_CTL);
+          return EOVAE_ERR_UNSUPPORTED;
+        }
+        if (hipMalloc((void**)&ticket_block, 256) != hipSuccess || hipMemsetAsync(ticket_block, 0, 256, st) != hipSuccess) {
+          eovae_set_error("gn_silu_bwd: cannot allocate the ticket counter");
+          return EOVAE_ERR_LAUNCH;
+        }
+        g_gn_ctl[g_gn_nctl].dev = dev;
+        g_gn_ctl[g_gn_nctl].st = st;
+        g_gn_ctl[g_gn_nctl].block = ticket_block;
+        ++g_gn_nctl;
+      }
+    }
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
     GnBwdFArgs a;
     a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.stats = stats; a.dx_add = dx_add; a.dx = dx;
     const GnBwdWs w = gn_bwd_ws(N, C, HW, G);
-    static unsigned* tickets[64] = {nullptr};   // one zero-initialised counter per device, reset by every finalize launch
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
-      eovae_set_error("gn_silu_bwd: device index");
-      return EOVAE_ERR_LAUNCH;
-    }
-    if (!tickets[dev]) {
-      if (hipMalloc((void**)&tickets[dev], 256) != hipSuccess || hipMemset(tickets[dev], 0, 256) != hipSuccess) {
-        tickets[dev] = nullptr;
-        eovae_set_error("gn_silu_bwd: cannot allocate the ticket counter");
-        return EOVAE_ERR_LAUNCH;
-      }
-    }
-    a.ticket = tickets[dev];
+    a.ticket = ticket_block;
     a.team = (i32x4*)((char*)ws + w.team);
     a.part = (float2*)((char*)ws + w.part);
     a.amax_part = dx_amax_bits ? (float*)((char*)ws + w.amax) : nullptr;
@@ -966,7 +1025,7 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
 #undef EOVAE_GN_PICK
     hipLaunchKernelGGL(k, dim3(plan.grid), dim3(GNF_NT), 0, st, a);
     hipLaunchKernelGGL(gn_bwd_fused_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, a.part, dgamma, dbeta,
-                       a.amax_part, plan.grid * (GNF_NT / 64), dx_amax_bits, a.err, a.token, N, C, HW, cpg, a.ticket);
+                       a.amax_part, plan.grid * (GNF_NT / 64), dx_amax_bits, a.err, a.token, N, C, HW, cpg, a.ticket, sticky_dev);
     EOVAE_CHECK_LAUNCH("eovae_gn_silu_bwd (fused)");
     return EOVAE_OK;
   }

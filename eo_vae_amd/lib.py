@@ -21,6 +21,7 @@ SIGNATURES = {
     'eovae_last_error': (C.c_char_p, []),
     'eovae_abi_version': (_i, []),
     'eovae_target_arch': (C.c_char_p, []),
+    'eovae_clock_probe': (_i, [_p, _p, _i, _i, _p]),
     'eovae_set_option': (_i, [C.c_char_p, _i]),
     'eovae_get_option': (_i, [C.c_char_p]),
     'eovae_conv_packed_dims': (_i, [_i, _i, _i, _i, _i, _ip, _ip]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     'eovae_conv3x3_thin_fwd_eligible': (_i, [_i, _i, _i, _i, _i]),
     'eovae_conv3x3_thin_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_gn_bwd_fused': (_i, [_i]),
+    'eovae_gn_bwd_timeouts': (C.c_ulonglong, [_i]),
     'eovae_gn_bwd_fused_eligible': (_i, [_i, _i, _i, _i]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),

@@ -807,6 +807,17 @@ class GroupNormSiluFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+def raise_on_gn_backward_timeouts():
+    """Once per step (training_step): a team of the one-pass GroupNorm backward that timed out has poisoned its
+    dgamma / dbeta with NaN; the kernels also leave the event in a host-visible word.  Raises instead of letting the
+    optimiser write NaN into every weight.  Sees every launch the host has synchronised with -- at the
+    latest one step after the event."""
+    tok = L.load().eovae_gn_bwd_timeouts(1)
+    if tok:
+        raise L.EovaeError(f'GroupNorm backward: a workgroup team timed out waiting for its partial sums (token {tok:#x}); '
+                           'the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
+
+
 def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
     """packed=True: the result is handed over as f16c8 operand records (see mark_packed) -- only for a
     consumer that is a plain 3x3 Conv2dFn in f16c8 mode."""

@@ -32,6 +32,10 @@ const char* eovae_target_arch(void); /* "gfx950" */
  * environment variable, read once; afterwards only eovae_set_option changes it.  Returns 0 / the value, or a negative
  * status for an unknown name.  Options: "c8_wgrad_rows" (EOVAE_C8_WGRAD_ROWS, default 1): plain 3x3 weight gradients
  * with record input run the row-streaming kernel instead of the tile kernel. */
+/* Diagnostic (csrc/diag.hip): the shader clock the chip holds under a dense f16-MFMA load.  Every workgroup (512 threads,
+ * one per CU) runs `iters` rounds of 16 MFMAs per wave and writes {shader cycles, 100-MHz wall ticks} of its loop to
+ * out[2 b], out[2 b + 1]: clock = cycles / ticks x 0.1 GHz.  Touches no product tensor. */
+int eovae_clock_probe(unsigned long long* out, float* sink, int blocks, int iters, void* stream);
 int eovae_set_option(const char* name, int value);
 int eovae_get_option(const char* name);
 
@@ -198,6 +202,11 @@ int eovae_gn_silu_fwd(const float* x, const float* gamma, const float* beta, flo
  * force (-1 = undecided: environment EOVAE_GN_BWD_FUSED, default on, is read at first use).
  * eovae_gn_bwd_fused_eligible: 1 when eovae_gn_silu_bwd takes that kernel for the shape (HW % 1024 == 0, team <= 2 x CUs). */
 int eovae_gn_bwd_fused(int on);
+/* Time-outs of the one-pass kernel's team hand-off on the current device since the last clear (0 = none, else the token
+ * of the latest).  The word is host memory the kernels write through, so the call costs nothing and sees every launch the
+ * caller has synchronised with; a trainer checks it once per step (a time-out also poisons that call's dgamma / dbeta
+ * with NaN).  clear != 0 resets it. */
+unsigned long long eovae_gn_bwd_timeouts(int clear);
 int eovae_gn_bwd_fused_eligible(int N, int C, int HW, int G);
 /* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C]; dx_amax_bits (nullable, device): receives the
  * float bits of max|dx| -- the pre-scale input of eovae_conv3x3_f16c8_fwd's data-gradient calls, produced

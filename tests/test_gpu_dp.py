@@ -112,8 +112,11 @@ def test_two_rank_train_step_on_one_gpu(mods):
         opt.flat.gather()           # single-process path: parameter gradients -> flat buffer
         grads.append(opt.flat.grad.detach().cpu().clone())
     avg = (grads[0] + grads[1]) / 2
-    # averaged gradient (atomics in wgrad make the last bits run-dependent)
-    assert (g0 - avg).norm() / avg.norm() < 1e-4
+    # averaged gradient: the plain 3x3 weight gradients are bit-reproducible (fixed-order fold); float atomics remain in the
+    # 1x1 / sub-pixel / stride-2 weight gradients and the bias gradients, so the last bits are still run-dependent
+    e_avg = float((g0 - avg).norm() / avg.norm())
+    print(f'averaged gradient vs single-process average: {e_avg:.2e}')
+    assert e_avg < 2e-5
 
 
 def _rccl_worker(port, q):
@@ -164,9 +167,12 @@ def test_rccl_world_of_one_matches_plain_step():
     for a, b in zip(loss_a, loss_b):
         assert abs(a - b) <= 1e-5 * abs(a)
     pa, pb = torch.from_numpy(par_a), torch.from_numpy(par_b)
-    # AVG over one rank is the identity: only wgrad's atomic ordering differs between the two runs;
-    # the first Adam steps move every entry by ~lr whatever |g| is, so compare in units of lr = 1e-3
-    assert (pa - pb).abs().max() < 2.5e-3 and ((pa - pb).abs() > 2e-4).float().mean() < 0.01
+    # AVG over one rank is the identity: only the order of the float atomics that are left (1x1 / sub-pixel / stride-2
+    # weight gradients, bias gradients; the plain 3x3 weight gradients fold in a fixed order) differs between the two
+    # runs; the first Adam steps move every entry by ~lr whatever |g| is, so compare in units of lr = 1e-3
+    d = (pa - pb).abs()
+    print(f'parameters after the steps: max |diff| {float(d.max()):.2e}, share above 2e-4: {float((d > 2e-4).float().mean()):.2e}')
+    assert d.max() < 2.5e-3 and (d > 2e-4).float().mean() < 0.01
 
 
 @pytest.mark.timeout(900)

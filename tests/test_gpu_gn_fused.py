@@ -166,3 +166,34 @@ def test_one_pass_backward_replays_inside_a_hip_graph(fused_switch):
         torch.cuda.synchronize()
         lib.eovae_gn_bwd_fused(2)
         assert rel_err(got[0], dx) < 2e-6 and rel_err(got[1], dg) < 2e-6 and rel_err(got[2], db) < 2e-6, r
+
+
+def test_two_streams_use_separate_control_blocks_and_no_timeout_is_recorded(fused_switch):
+    """the ticket counter / epoch of the hand-off protocol is per (device, STREAM), so backward passes enqueued
+    on two streams at once do not draw tickets from one counter (their teams would interleave and time out); a time-out
+    would land in the host-visible word eovae_gn_bwd_timeouts reads, which training_step checks once per step."""
+    from eo_vae_amd import ops
+    lib = fused_switch
+    lib.eovae_gn_bwd_fused(2)
+    lib.eovae_gn_bwd_timeouts(1)
+    n, c, groups, h, w = 4, 128, 32, 128, 128
+    x = hashed((n, c, h, w), 901, 1.0).cuda()
+    g = (1.0 + hashed((c,), 902, 0.2)).cuda()
+    b = hashed((c,), 903, 0.2).cuda()
+    gy = hashed((n, c, h, w), 904, 1e-3).cuda()
+    ref = run(lib, 2, x, g, b, gy, None, groups, True, False)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                xg, gg, bg = [t.clone().requires_grad_(True) for t in (x, g, b)]
+                ops.group_norm_silu(xg, gg, bg, groups, 1e-6, True).backward(gy)
+                outs[i] = (xg.grad, gg.grad, bg.grad)
+    torch.cuda.synchronize()
+    for o in outs:
+        for a_, r_ in zip(o, ref[:3]):
+            assert torch.equal(a_, r_)            # fixed summation order: bit-identical whichever stream ran it
+    assert lib.eovae_gn_bwd_timeouts(0) == 0
+    ops.raise_on_gn_backward_timeouts()           # no-op without a time-out

@@ -164,7 +164,11 @@ def test_full_size_kernel_properties():
     w.grad = None; b.grad = None
     xb = x1.clone().requires_grad_(True)
     ops.conv2d(xb, w, b, None, 'normal').backward(-3.0 * gy)
-    assert rel(xb.grad, -3.0 * gx_a) < 5e-5 and rel(w.grad, -3.0 * gw_a) < 1e-4    # linear in dy (atomics reorder)
+    e_x, e_w = rel(xb.grad, -3.0 * gx_a), rel(w.grad, -3.0 * gw_a)
+    print(f'linear in dy: dx {e_x:.2e}, dw {e_w:.2e}')
+    # linear in dy: the plain weight gradient sums in a fixed order (no atomics since round 3); what is left is the
+    # arithmetic -- a 3 x larger dy takes another power-of-two pre-scale, i.e. other f16 / fp8 roundings
+    assert e_x < 5e-5 and e_w < 5e-5
     assert rel(gb_a, gy.sum((0, 2, 3))) < 2e-5
     del xa, xb, ya, y1, y2, y12
     gamma = torch.randn(C, device='cuda'); beta = torch.randn(C, device='cuda')
