@@ -34,10 +34,15 @@ _ZERO_POOL_ELEMS = 1 << 18
 def zeros_small(numel: int, dtype, device) -> torch.Tensor:
     """A zeroed 1-d tensor for a small accumulator (GroupNorm sums, bias gradients): a never-reused slice of a pool
     that ONE fill kernel zeroed, instead of a 5-9 us fill launch per accumulator (about 110 per step).  A slice is
-    handed out once; a used-up pool is dropped (it lives on while slices of it do)."""
+    handed out once; a used-up pool is dropped (it lives on while slices of it do).  NOTE for bias gradients: autograd
+    keeps the slice as the parameter's .grad, i.e. a view into a 1 MiB pool that stays alive with it -- FlatParams
+    gathers and drops those gradients every step; a caller that keeps or pickles .grad tensors should clone them."""
     if numel > _ZERO_POOL_ELEMS // 8:
         return torch.zeros(numel, dtype=dtype, device=device)
-    key = (device.type, device.index, dtype)
+    # one pool per (device, dtype, STREAM, inference mode): a pool is zero-filled on the stream current at its creation,
+    # and a pool created under torch.inference_mode() is an inference tensor that a later train-mode step must not reuse
+    key = (device.type, device.index, dtype, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0,
+           torch.is_inference_mode_enabled())
     pool, off = _ZERO_POOL.get(key, (None, 0))
     step = (numel + 63) // 64 * 64            # keep every slice 256-byte aligned
     if pool is None or off + step > pool.numel():
@@ -375,12 +380,46 @@ class WeightPrepack:
         return [w.data_ptr() for w in self.weights] != self.ptrs
 
     def run(self):
-        global _ACTIVE_PREPACK
+        """Enqueue the two pack launches on a SIDE stream (they are HBM-bound, ~0.9 ms at B = 16 model size, and the step
+        opens with the encoder's kernel generator: ~100 five-microsecond launches that leave the chip idle): the first
+        convolution that asks for a pack makes its stream wait for the packs' event."""
+        global _ACTIVE_PREPACK, _PREPACK_STREAM
         if self.desc is None:
             return
-        L.check(L.load().eovae_conv3x3_f16c8_pack_multi(L.ptr(self.desc), len(self.ptrs), 1.0, L.stream()),
-                'eovae_conv3x3_f16c8_pack_multi')
-        _ACTIVE_PREPACK = self.packs
+        main = torch.cuda.current_stream()
+        if PREPACK_SIDE_STREAM:
+            if _PREPACK_STREAM is None:
+                _PREPACK_STREAM = torch.cuda.Stream()
+                from .parallel import SIDE_STREAMS
+                SIDE_STREAMS.append(_PREPACK_STREAM)
+            side = _PREPACK_STREAM
+            side.wait_stream(main)      # the optimiser step that wrote the weights; last step's convolutions that read the packs
+            with torch.cuda.stream(side):
+                L.check(L.load().eovae_conv3x3_f16c8_pack_multi(L.ptr(self.desc), len(self.ptrs), 1.0, L.stream()),
+                        'eovae_conv3x3_f16c8_pack_multi')
+                self.event = side.record_event()
+        else:
+            L.check(L.load().eovae_conv3x3_f16c8_pack_multi(L.ptr(self.desc), len(self.ptrs), 1.0, L.stream()),
+                    'eovae_conv3x3_f16c8_pack_multi')
+            self.event = None
+        # a pack is only handed out for the very tensor it was made from: same storage, shape and version (ADVICE r3: a
+        # slice sharing offset 0, or an in-place edit between run() and the convolution, must not get this pack)
+        self.versions = {w.data_ptr(): (tuple(w.shape), w._version) for w in self.weights}
+        self.waited = set()
+        _ACTIVE_PREPACK = self
+
+    def lookup(self, weight):
+        hit = self.packs.get(weight.data_ptr())
+        if hit is None or self.versions.get(weight.data_ptr()) != (tuple(weight.shape), weight._version):
+            return None
+        if self.event is not None:       # a stream's first consumer makes it wait for the packs (later ones follow in order)
+            cs = torch.cuda.current_stream()
+            if cs.cuda_stream not in self.waited:
+                cs.wait_event(self.event)
+                self.waited.add(cs.cuda_stream)
+        return hit
+
+    event = None
 
     @staticmethod
     def release():
@@ -389,13 +428,17 @@ class WeightPrepack:
 
 
 _ACTIVE_PREPACK = None
+_PREPACK_STREAM = None
 PREPACK = os.environ.get('EOVAE_PREPACK', '1') != '0'
+# EOVAE_PREPACK keeps both orientations of every plain 3x3 weight packed for the whole run (~8 bytes per weight element:
+# 0.7 GB for the full-size model) instead of transient per-layer buffers.
+PREPACK_SIDE_STREAM = os.environ.get('EOVAE_PREPACK_STREAM', '1') != '0'
 
 
 def pack_pair_f16c8(weight):
     """(forward, data-gradient) f16c8 weight packs of one plain 3x3 layer from ONE amax pass."""
     if _ACTIVE_PREPACK is not None:
-        hit = _ACTIVE_PREPACK.get(weight.data_ptr())
+        hit = _ACTIVE_PREPACK.lookup(weight)
         if hit is not None:
             return hit
     lib = L.load()

@@ -116,7 +116,7 @@ def test_two_rank_train_step_on_one_gpu(mods):
     # 1x1 / sub-pixel / stride-2 weight gradients and the bias gradients, so the last bits are still run-dependent
     e_avg = float((g0 - avg).norm() / avg.norm())
     print(f'averaged gradient vs single-process average: {e_avg:.2e}')
-    assert e_avg < 2e-5
+    assert e_avg < 2e-6            # measured 8e-8 (profiles/r04k)
 
 
 def _rccl_worker(port, q):
@@ -172,7 +172,7 @@ def test_rccl_world_of_one_matches_plain_step():
     # runs; the first Adam steps move every entry by ~lr whatever |g| is, so compare in units of lr = 1e-3
     d = (pa - pb).abs()
     print(f'parameters after the steps: max |diff| {float(d.max()):.2e}, share above 2e-4: {float((d > 2e-4).float().mean()):.2e}')
-    assert d.max() < 2.5e-3 and (d > 2e-4).float().mean() < 0.01
+    assert d.max() < 1e-3 and (d > 2e-4).float().mean() < 1e-3      # measured: max 1.8e-4, none above 2e-4 (r04k)
 
 
 @pytest.mark.timeout(900)

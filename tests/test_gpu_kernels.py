@@ -357,6 +357,19 @@ def test_weight_prepack_equals_the_per_layer_packs():
                 assert torch.equal(ref[:nb], got[:nb]), (co, ci, flip)
     finally:
         ops.WeightPrepack.release()
+    # a pack is handed out only for the tensor it was made from -- a view that shares offset 0 but not the
+    # shape, or a weight edited in place after run(), falls through to the per-layer pack
+    pp.run()
+    try:
+        view = ws[0][:64]
+        assert view.data_ptr() == ws[0].data_ptr()
+        assert ops.pack_pair_f16c8(view)[0].data_ptr() != pp.packs[ws[0].data_ptr()][0].data_ptr()
+        assert ops.pack_pair_f16c8(ws[3])[0].data_ptr() == pp.packs[ws[3].data_ptr()][0].data_ptr()
+        ws[3].mul_(2.0)
+        assert ops.pack_pair_f16c8(ws[3])[0].data_ptr() != pp.packs[ws[3].data_ptr()][0].data_ptr()
+    finally:
+        ops.WeightPrepack.release()
+    torch.cuda.synchronize()
     ws[1] = ws[1].clone()                      # a weight whose storage moved
     pp.weights[1] = ws[1]
     assert pp.stale()
