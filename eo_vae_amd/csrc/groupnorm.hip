@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void amax_fold_kernel(const float* __restrict_
 // Progress: logical workgroup ids are tickets taken in order of ARRIVAL, so the workgroups that are resident always
 // hold the lowest ids, i.e. whole teams plus at most one partial team; a whole team needs nobody else, finishes and
 // frees its slots.  (grid <= workgroups-per-CU x CUs, so normally everything is resident anyway; the tickets cover a GPU
-// shared with another process or with RCCL's kernels.)  The wait is bounded all the same (4e9 shader clocks, ~2 s):
+// shared with another process or with RCCL's kernels.)  The wait is bounded all the same (two seconds of s_memrealtime, gnf_timed_out):
 // on a time-out the workgroup records the token in `err`, and the finalize kernel poisons dgamma / dbeta with NaN.
 // The per-channel partials (for dgamma / dbeta) are plain stores, read by the finalize kernel after the launch.
 // Two forms: gn_bwd_fused_kernel (one slab per workgroup in flight; A/B reference, and the form for slabs whose team
@@ -356,6 +356,20 @@ struct GnBwdFArgs {
   int C, HW, cpg, G, T, nteams, NG;
   float inv_count;
 };
+
+// Bounded wait of the hand-off: two seconds on the constant 100-MHz clock (s_memrealtime), confirmed by a second reading.
+// Round 4: the bound used to be 4e9 SHADER cycles (s_memtime) and fired spuriously in about every second bench.py run
+// -- no wave had waited anywhere near two seconds (the runs were not that long); the shader-clock counter is not a
+// trustworthy interval across the chip's clock-state changes.  A reading that jumps backwards or by more than 2^40
+// ticks (three hours) restarts the window instead of ending the wait.
+__device__ __forceinline__ bool gnf_timed_out(unsigned long long& t0) {
+  const unsigned long long d = __builtin_amdgcn_s_memrealtime() - t0;
+  if (d <= 200000000ull) return false;
+  if (d >= (1ull << 40)) { t0 = __builtin_amdgcn_s_memrealtime(); return false; }
+  __builtin_amdgcn_s_sleep(8);
+  const unsigned long long d2 = __builtin_amdgcn_s_memrealtime() - t0;
+  return d2 > 200000000ull && d2 < (1ull << 40);
+}
 
 // The token of THIS launch: the host's per-call value advanced by a device-side epoch that the finalize kernel bumps
 // at the end of every call.  A HIP graph replays a captured launch with its kernel arguments frozen -- without the
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
       if (lane == 0) granule_store(tg + member, (float)t1, (float)t2, token);
       // ---- wait for the team, fold its granules (fixed order: deterministic)
       double m1 = 0, m2 = 0;
-      const unsigned long long t0 = __builtin_readcyclecounter();   // s_memtime
+      unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100-MHz wall clock
       bool late = false;
       for (int j = lane; j < (EOVAE_GN_NOSYNC ? 0 : a.T); j += 64) {
         i32x4 gv;
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
           gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
           if (tk == token) break;
-          if (__builtin_readcyclecounter() - t0 > 4000000000ull) { late = true; break; }
+          if (gnf_timed_out(t0)) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         m1 += (double)bits_f(gv[0]);
@@ -632,7 +646,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
     if (wave == 0) {
       const i32x4* tg = a.team + (size_t)s * a.T;
       double m1 = 0, m2 = 0;
-      const unsigned long long t0 = __builtin_readcyclecounter();
+      unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       bool late = false;
       for (int j = lane; j < (EOVAE_GN_NOSYNC ? 0 : a.T); j += 64) {
         i32x4 gv;
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
           gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
           if (tk == token) break;
-          if (__builtin_readcyclecounter() - t0 > 4000000000ull) { late = true; break; }
+          if (gnf_timed_out(t0)) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         m1 += (double)bits_f(gv[0]);

@@ -380,9 +380,8 @@ class WeightPrepack:
         return [w.data_ptr() for w in self.weights] != self.ptrs
 
     def run(self):
-        """Enqueue the two pack launches on a SIDE stream (they are HBM-bound, ~0.9 ms at B = 16 model size, and the step
-        opens with the encoder's kernel generator: ~100 five-microsecond launches that leave the chip idle): the first
-        convolution that asks for a pack makes its stream wait for the packs' event."""
+        """Enqueue the two pack launches -- on the current stream, or (EOVAE_PREPACK_STREAM=1) on a side stream, in which case
+        the first convolution that asks for a pack makes its stream wait for the packs' event."""
         global _ACTIVE_PREPACK, _PREPACK_STREAM
         if self.desc is None:
             return
@@ -432,7 +431,10 @@ _PREPACK_STREAM = None
 PREPACK = os.environ.get('EOVAE_PREPACK', '1') != '0'
 # EOVAE_PREPACK keeps both orientations of every plain 3x3 weight packed for the whole run (~8 bytes per weight element:
 # 0.7 GB for the full-size model) instead of transient per-layer buffers.
-PREPACK_SIDE_STREAM = os.environ.get('EOVAE_PREPACK_STREAM', '1') != '0'
+# EOVAE_PREPACK_STREAM=1: the two pack launches on a side stream, overlapping the encoder generator's head.  Measured
+# (profiles/r04n_prepack_stream_ab.log, same box, alternating): 97.4-97.6 ms on the main stream, 97.6-98.1 on the side stream
+# -- the packs' weight reads then miss the L2 the convolutions find them in.  Off by default.
+PREPACK_SIDE_STREAM = os.environ.get('EOVAE_PREPACK_STREAM', '0') != '0'
 
 
 def pack_pair_f16c8(weight):
@@ -856,6 +858,9 @@ def raise_on_gn_backward_timeouts():
     optimiser write NaN into every weight.  Sees every launch the host has synchronised with -- at the
     latest one step after the event."""
     tok = L.load().eovae_gn_bwd_timeouts(1)
+    if tok and os.environ.get('EOVAE_GN_TIMEOUT_ACTION') == 'warn':      # diagnosis only
+        print(f'[eo_vae_amd] GroupNorm backward time-out recorded (token {tok:#x})', flush=True)
+        return
     if tok:
         raise L.EovaeError(f'GroupNorm backward: a workgroup team timed out waiting for its partial sums (token {tok:#x}); '
                            'the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
