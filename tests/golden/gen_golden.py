@@ -75,8 +75,15 @@ def ref_defs_from_source(path, names, ns):
     """Execute selected top-level class / function definitions of a reference script that cannot be
     imported as a whole (same reason as ref_class_from_source)."""
     tree = ast.parse(open(path).read())
-    nodes = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
-    assert len(nodes) == len(names), [n.name for n in nodes]
+
+    def name_of(n):
+        if isinstance(n, (ast.ClassDef, ast.FunctionDef)):
+            return n.name
+        if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name):
+            return n.targets[0].id      # module-level tables (WAVELENGTHS, NORM_STATS_LEGACY)
+        return None
+    nodes = [n for n in tree.body if name_of(n) in names]
+    assert sorted(name_of(n) for n in nodes) == sorted(names), [name_of(n) for n in nodes]
     exec(compile(ast.Module(body=nodes, type_ignores=[]), path, 'exec'), ns)
     return [ns[n] for n in names]
 
@@ -714,6 +721,31 @@ def batch_prep():
         hf, vf, k = random.random() > 0.5, random.random() > 0.5, random.randint(0, 3)
         arrays[f'draw{seed}'] = np.array([int(hf), int(vf), k])
         arrays[f'out{seed}'] = npy(out)
+    # round 4: the other normalisers and the random-modality collate itself, from the reference's source
+    import numpy
+    ns2 = {'torch': torch, 'nn': torch.nn, 'random': random, 'np': numpy}
+    names = ['WAVELENGTHS', 'NORM_STATS_LEGACY', 'Sentinel2L2ANorm', 'Sentinel2L1CNorm', 'LegacyZScoreNorm', 'NormalizerFactory',
+             'apply_batch_augmentations', 'single_modality_collate_fn']
+    ref = dict(zip(names, ref_defs_from_source(os.path.join(REF, 'eo_vae', 'datasets', 'terramesh_datamodule.py'), names, ns2)))
+    raw_l1c = hashed((2, 13, 20, 28), 812, 1.0) * 3500.0 + 2500.0
+    raw_s1 = hashed((2, 2, 20, 28), 813, 1.0) * 6.0 - 14.0          # dB
+    arrays['raw_l1c'], arrays['raw_s1rtc'] = npy(raw_l1c), npy(raw_s1)
+    arrays['norm_l1c_custom'] = npy(ref['Sentinel2L1CNorm']()(raw_l1c))
+    arrays['norm_s1rtc_legacy'] = npy(ref['LegacyZScoreNorm']('S1RTC')(raw_s1))
+    arrays['norm_l2a_legacy'] = npy(ref['NormalizerFactory'].create('S2L2A', 'legacy')(raw))
+    assert type(ref['NormalizerFactory'].create('S1RTC', 'custom')).__name__ == 'LegacyZScoreNorm'   # the fall-back (:320-327)
+    # single_modality_collate_fn(['S2L2A', 'S1RTC'], custom scheme, target 24 x 32, train) on the raw batch, 8 seeds
+    collate = ref['single_modality_collate_fn'](['S2L2A', 'S1RTC'], normalize=True, norm_scheme='custom', target_size=(24, 32),
+                                                mode='train')
+    for seed in range(8):
+        random.seed(100 + seed)
+        out = collate({'S2L2A': raw.clone(), 'S1RTC': raw_s1.clone()})
+        arrays[f'collate{seed}_image'] = npy(out['image'])
+        arrays[f'collate{seed}_wvs'] = npy(out['wvs'])
+        arrays[f'collate{seed}_modality'] = np.array(out['modality'])
+    # eval mode, one modality, key 'image', legacy scheme, no resize
+    collate1 = ref['single_modality_collate_fn'](['S2L1C'], normalize=True, norm_scheme='legacy', target_size=None, mode='eval')
+    arrays['collate_eval_l1c'] = npy(collate1({'image': raw_l1c.clone()})['image'])
     save('batch_prep', **arrays)
 
 

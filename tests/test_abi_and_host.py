@@ -335,3 +335,48 @@ def test_zero_pool_hands_out_disjoint_zeroed_slices():
         e.fill_(3.0)
     assert e.untyped_storage().data_ptr() != first and float(a.sum()) == 5.0
     ops._ZERO_POOL.clear()
+
+
+def test_batch_prep_host_logic_against_the_reference_collate(golden, monkeypatch):
+    """N2 host side on the CPU: data.norm_table = the reference's NormalizerFactory tables, and data.GpuBatchPrep draws the
+    modality and the D4 element in the reference's order (fixture: the reference's single_modality_collate_fn,
+    terramesh_datamodule.py:418-503).  The HIP launch is replaced by the same arithmetic in torch (no GPU here); the GPU
+    test (test_gpu_kernels2.py) runs the kernel against the same fixture."""
+    import random
+    import numpy as np
+    import pytest
+    import torch
+    import torch.nn.functional as F
+    from eo_vae_amd import data as D
+    g = golden('batch_prep')
+
+    def cpu_prepare(raw, mean=None, std=None, clamp=None, target_size=None, hflip=False, vflip=False, rot=0):
+        x = raw.float()
+        if clamp is not None:
+            x = torch.clamp(x, clamp[0], clamp[1])
+        if mean is not None:
+            x = (x - mean.view(-1, 1, 1)) / std.view(-1, 1, 1)
+        if target_size is not None:
+            x = F.interpolate(x, size=tuple(target_size), mode='bilinear', align_corners=False)
+        if hflip:
+            x = torch.flip(x, dims=[-1])
+        if vflip:
+            x = torch.flip(x, dims=[-2])
+        return torch.rot90(x, rot, dims=[-2, -1]) if rot else x
+    monkeypatch.setattr(D, 'prepare_batch', cpu_prepare)
+    T = lambda a: torch.from_numpy(np.asarray(a))                                                             # noqa: E731
+    for mod, scheme, key_raw, key_out in (('S2L1C', 'custom', 'raw_l1c', 'norm_l1c_custom'), ('S1RTC', 'legacy', 'raw_s1rtc', 'norm_s1rtc_legacy'),
+                                          ('S2L2A', 'legacy', 'raw', 'norm_l2a_legacy'), ('S1RTC', 'custom', 'raw_s1rtc', 'norm_s1rtc_legacy')):
+        mean, div, clamp = D.norm_table(mod, scheme)
+        got = cpu_prepare(T(g[key_raw]), mean, div, clamp)
+        assert (got - T(g[key_out])).abs().max().item() < 1e-6, (mod, scheme)
+    with pytest.raises(ValueError):
+        D.norm_table('S1GRD', 'legacy')
+    prep = D.GpuBatchPrep(['S2L2A', 'S1RTC'], normalize=True, norm_scheme='custom', target_size=(24, 32), mode='train',
+                          device=torch.device('cpu'))
+    raw = {'S2L2A': T(g['raw']), 'S1RTC': T(g['raw_s1rtc'])}
+    for seed in range(8):
+        random.seed(100 + seed)
+        out = prep(raw)
+        assert out['modality'] == str(g[f'collate{seed}_modality'])
+        assert (out['image'] - T(g[f'collate{seed}_image'])).abs().max().item() < 2e-5
