@@ -44,6 +44,8 @@ class FCResLayer(nn.Module):  # :336-366
 # copies; the same post-norm layer written out on the same parameters needs 13 (one in_proj GEMM, a scaled
 # batched QK^T, softmax, PV, one head-merge copy, out_proj, add, LayerNorm, FFN GEMM + GELU + GEMM, add, LayerNorm).
 FAST_GENERATOR = os.environ.get('EOVAE_FAST_GENERATOR', '1') != '0'
+_TIMING_ONLY_FREEZE = os.environ.get('EOVAE_TIMING_FREEZE_GENERATORS', '0') == '1'
+DEAD_ROW_ELIMINATION = os.environ.get('EOVAE_GENERATOR_DEAD_ROWS', '1') != '0'   # 0: the last layer computes all rows
 
 # The hyper-network's GEMMs are 132-row problems ([132, 256] x [256, 256 .. 2048]).  PyTorch-ROCm's default BLAS
 # (hipBLASLt) picks 256-row macro tiles for them: 19-40 us per call where rocBLAS needs 7-10 (tools/gen_kernels.py).
@@ -79,18 +81,37 @@ def generator_blas_backend():
     return _BLAS_STATE['backend']
 
 
-def _encoder_layer(layer, x):
+def _encoder_layer(layer, x, keep_from=0):
     """nn.TransformerEncoderLayer.forward for an unbatched [L, d] input, post-norm, exact GELU, dropout 0
-    (the configuration of dynamic_conv.py:86-101), on the layer's own parameters."""
+    (the configuration of dynamic_conv.py:86-101), on the layer's own parameters.
+
+    keep_from > 0 (LAST layer of a generator): only the output rows keep_from .. L - 1 are computed.  The generators read
+    nothing but the wavelength rows and the bias row of the final output (dynamic_conv.py:121-130, 173-183), every op
+    behind the attention scores is row-wise, so the other rows' queries, out_proj, LayerNorms and FFN are dead work
+    (128 of 132 rows at C = 3: a quarter of a 4-layer generator, forward and backward); the kept rows see the same
+    arithmetic (a library GEMM may block 4 rows differently from 132: last-bit differences)."""
     att = layer.self_attn
     seq_len, d = x.shape
     h = att.num_heads
     dh = d // h
-    qkv = F.linear(x, att.in_proj_weight, att.in_proj_bias).view(seq_len, 3, h, dh)
-    q, k, v = (qkv[:, i].transpose(0, 1) for i in range(3))                  # [h, L, dh] strided views
-    s = torch.baddbmm(torch.empty(h, seq_len, seq_len, dtype=x.dtype, device=x.device), q, k.transpose(1, 2),
-                      beta=0.0, alpha=float(dh) ** -0.5)
-    o = torch.bmm(torch.softmax(s, dim=-1), v).transpose(0, 1).reshape(seq_len, d)
+    if keep_from > 0:
+        wq, wkv = att.in_proj_weight[:d], att.in_proj_weight[d:]
+        bq, bkv = att.in_proj_bias[:d], att.in_proj_bias[d:]
+        xq = x[keep_from:]
+        nq = seq_len - keep_from
+        q = F.linear(xq, wq, bq).view(nq, h, dh).transpose(0, 1)                # [h, nq, dh]
+        kv = F.linear(x, wkv, bkv).view(seq_len, 2, h, dh)
+        k, v = kv[:, 0].transpose(0, 1), kv[:, 1].transpose(0, 1)              # [h, L, dh]
+        s = torch.baddbmm(torch.empty(h, nq, seq_len, dtype=x.dtype, device=x.device), q, k.transpose(1, 2),
+                          beta=0.0, alpha=float(dh) ** -0.5)
+        o = torch.bmm(torch.softmax(s, dim=-1), v).transpose(0, 1).reshape(nq, d)
+        x = xq
+    else:
+        qkv = F.linear(x, att.in_proj_weight, att.in_proj_bias).view(seq_len, 3, h, dh)
+        q, k, v = (qkv[:, i].transpose(0, 1) for i in range(3))                  # [h, L, dh] strided views
+        s = torch.baddbmm(torch.empty(h, seq_len, seq_len, dtype=x.dtype, device=x.device), q, k.transpose(1, 2),
+                          beta=0.0, alpha=float(dh) ** -0.5)
+        o = torch.bmm(torch.softmax(s, dim=-1), v).transpose(0, 1).reshape(seq_len, d)
     x = F.layer_norm(x + F.linear(o, att.out_proj.weight, att.out_proj.bias), (d,), layer.norm1.weight,
                      layer.norm1.bias, layer.norm1.eps)
     f = F.linear(F.gelu(F.linear(x, layer.linear1.weight, layer.linear1.bias)), layer.linear2.weight,
@@ -126,14 +147,17 @@ class TransformerWeightGenerator(nn.Module):  # :62-130
         seq = torch.cat([self.weight_tokens, waves, self.bias_token], dim=0)
         enc = self.transformer_encoder
         if FAST_GENERATOR and enc.norm is None and all(_layer_is_plain(lyr) for lyr in enc.layers):
-            for lyr in enc.layers:
-                seq = _encoder_layer(lyr, seq)
-            return seq
-        return enc(seq)  # unbatched [L, d]
+            n = len(enc.layers)
+            for i, lyr in enumerate(enc.layers):   # the last layer only computes the rows the generator reads
+                seq = _encoder_layer(lyr, seq, self.wt_num if (i == n - 1 and DEAD_ROW_ELIMINATION) else 0)
+            if DEAD_ROW_ELIMINATION:
+                return seq                          # rows wt_num .. L - 1
+            return seq[self.wt_num:]
+        return enc(seq)[self.wt_num:]  # unbatched [L, d]
 
     def forward(self, waves):
-        out = self._tokens(waves)
-        return self.fc_weight(out[self.wt_num:-1] + waves), self.fc_bias(out[-1])
+        out = self._tokens(waves)                   # [C + 1, d]: the wavelength rows and the bias row
+        return self.fc_weight(out[:-1] + waves), self.fc_bias(out[-1])
 
 
 class TransformerWeightGenerator_decoder(TransformerWeightGenerator):  # :133-183
@@ -141,7 +165,7 @@ class TransformerWeightGenerator_decoder(TransformerWeightGenerator):  # :133-18
 
     def forward(self, waves):
         out = self._tokens(waves)
-        wave_out = out[self.wt_num:-1]
+        wave_out = out[:-1]
         bias = self.fc_bias(wave_out + self.bias_token.repeat(waves.shape[0], 1))
         return self.fc_weight(wave_out + waves), bias
 
@@ -189,6 +213,14 @@ class _DynamicBase(nn.Module):
         its values, then registered under (1).  A key made of data_ptr/_version alone (round 1) handed
         a recycled address the previous wavelengths' kernels."""
         cacheable = not self.training and not torch.is_grad_enabled()
+        if _TIMING_ONLY_FREEZE:      # EOVAE_TIMING_FREEZE_GENERATORS=1: what the hyper-networks cost a step (timing experiment:
+            hit = self._gen_cache.get('frozen')   # generated kernels without their graph -- NO generator gradients)
+            if hit is None:
+                with torch.no_grad(), sdpa_kernel(SDPBackend.MATH):
+                    waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
+                    hit = tuple(t.detach() for t in self.weight_generator(self.fclayer(waves)))
+                self._gen_cache['frozen'] = hit
+            return hit
         if cacheable:
             hit = self._gen_cache.get(('id', id(wvs)))
             if hit is not None and hit[0] is wvs and hit[1] == wvs._version:

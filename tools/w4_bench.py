@@ -15,6 +15,8 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n
 
 shapes = [(128, 128, 256), (256, 256, 128), (512, 512, 64), (256, 128, 256), (512, 256, 128), (512, 512, 32)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
 B = 16
 lib = L.load()
 ops.CONV_PRECISION = 'f16c8'
