@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import eo_vae_cpu as O
-from tools.scheme_probe_cpu import bf16, e4m3, e5m2, f16, pow2_scale
+from tools.scheme_probe_cpu import bf16, e4m3, e5m2, f16, mx_quant, pow2_scale
 
 # operand kinds: 'act' = activation or gradient tensor (no amax known unless scaled), 'w' = weights
 
@@ -39,9 +39,36 @@ def make_f16c8(scale_acts):
     return split
 
 
+def make_mx(fmt, where=('fwd', 'dgrad', 'wgrad')):
+    """Round 4: f16 main product + the correction product on block-scaled `fmt` operands (per-32 E8M0 scales along the
+    K axis of the product: channels forward / data gradient, pixels of a row in the weight gradient) = 1.5 units.
+    `where`: the products that carry the correction at all (the others run plain f16: 1 unit)."""
+    def split(a, b, op, ka, kb):
+        kind = CUR['op']
+        da, db = CUR['kdims']
+        sa = pow2_scale(a, 2.0 ** 14) if ka == 'act' else pow2_scale(a, 2.0 ** 14)
+        sb = pow2_scale(b, 2.0 ** 14)
+        a_, b_ = a * sa, b * sb
+        ah, bh = f16(a_), f16(b_)
+        main = op(ah, bh)
+        if kind not in where:
+            return main / (sa * sb)
+        al, bl = a_ - ah, b_ - bh
+        corr = op(mx_quant(al, da, fmt), mx_quant(b_, db, fmt)) + op(mx_quant(a_, da, fmt), mx_quant(bl, db, fmt))
+        return (main + corr) / (sa * sb)
+    return split
+
+
 SPLITS = {'f32': lambda a, b, op, ka, kb: op(a, b), 'bf16x3': split_bf16x3,
-          'f16+c8 (dy scaled)': make_f16c8(True), 'f16+c8 (no act scale)': make_f16c8(False)}
-CUR = {'fn': None}
+          'f16+c8 (dy scaled)': make_f16c8(True), 'f16+c8 (no act scale)': make_f16c8(False),
+          'f16+mx e2m3 (1.5 u)': make_mx('e2m3'), 'f16+mx e3m2 (1.5 u)': make_mx('e3m2'), 'f16+mx e2m1 (1.5 u)': make_mx('e2m1'),
+          'f16+mx e2m3, dgrad plain f16 (1.33 u)': make_mx('e2m3', ('fwd', 'wgrad')),
+          'f16+c8 fwd/wgrad, dgrad plain f16 (1.67 u)': None}
+CUR = {'fn': None, 'op': 'fwd', 'kdims': (1, 1)}
+_C8 = make_f16c8(True)
+SPLITS['f16+c8 fwd/wgrad, dgrad plain f16 (1.67 u)'] = (
+    lambda a, b, op, ka, kb: (op(f16(a * pow2_scale(a, 2.0 ** 14)), f16(b * pow2_scale(b, 2.0 ** 14))) / (pow2_scale(a, 2.0 ** 14) * pow2_scale(b, 2.0 ** 14)))
+    if CUR['op'] == 'dgrad' else _C8(a, b, op, ka, kb))
 _orig = F.conv2d
 
 
@@ -50,13 +77,16 @@ class EmuConv(torch.autograd.Function):
     def forward(ctx, x, w, stride, padding):
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, padding)
+        CUR['op'], CUR['kdims'] = 'fwd', (1, 1)
         return CUR['fn'](x, w, lambda a, b: _orig(a, b, None, stride, padding), 'act', 'w')
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padding = ctx.sp
+        CUR['op'], CUR['kdims'] = 'dgrad', (1, 0)
         dx = CUR['fn'](dy, w, lambda a, b: torch.nn.grad.conv2d_input(x.shape, b, a, stride, padding), 'act', 'w')
+        CUR['op'], CUR['kdims'] = 'wgrad', (3, 3)
         dw = CUR['fn'](x, dy, lambda a, b: torch.nn.grad.conv2d_weight(a, w.shape, b, stride, padding), 'act', 'act')
         return dx, dw, None, None
 
