@@ -22,6 +22,11 @@ namespace {
 struct OptDef { const char* name; const char* env; int dflt; };
 const OptDef kOpts[EOVAE_OPT_COUNT] = {
     {"c8_wgrad_rows", "EOVAE_C8_WGRAD_ROWS", 1},   // row-streaming weight gradient (conv_f16c8_wgrad_rows.hip)
+    {"c8_w4", "EOVAE_C8_W4", -1},                  // conv_f16c8_w4.hip: -1 when it pays, 0 never, 1 whenever the shape allows
+    {"c8_w4_ni", "EOVAE_C8_W4_NI", 4},
+    {"c8_w4_stagger", "EOVAE_C8_W4_STAGGER", 0},
+    {"c8_w4_skew", "EOVAE_C8_W4_SKEW", -1},
+    {"c8_wgrad_w4", "EOVAE_C8_WGRAD_W4", 0},       // conv_f16c8_wgrad_w4.hip (parked: slower than the 8-wave kernels)
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};

@@ -1780,11 +1780,10 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   }
   // 16-row tiles while they still give every CU two tiles, else 8-row tiles
   const long long blocks16 = (long long)N * cdiv(Hout, 16) * a.tiles_x * a.ncob;
-  static const char* th_env = getenv("EOVAE_C8_TH");   // experiment hook: force the tile height
   // 8-row tiles only: the 16-row tile (half the weight traffic per MFMA) needs 128 accumulator + 40 staging
   // registers per lane and spilled into the loop
   const bool th16 = false;
-  (void)th_env; (void)blocks16;
+  (void)blocks16;
   a.tiles_y = cdiv(Hout, th16 ? 16 : 8);
   const long long sp_tiles = (long long)N * a.tiles_y * a.tiles_x;
   a.xcd_remap = xcd_ok(sp_tiles);

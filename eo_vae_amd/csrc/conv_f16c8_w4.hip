@@ -610,21 +610,20 @@ extern "C" int eovae_debug_w4_stamps(void* dst, size_t bytes) {
 // one block per CU (tools/w4_stamps.py).  fp32 inputs always take 4 rows per wave: the 2-row fp32
 // variant spills 50 registers into the phase sequence and is not used.
 static int w4_rows_per_wave(const ConvCArgs& a, int n_cu) {
-  const char* env = getenv("EOVAE_C8_W4_NI");
   (void)n_cu;
-  if (env && env[0] == '2' && a.packed && a.Hout % 8 == 0) return 2;
+  if (eovae_opt(EOVAE_OPT_C8_W4_NI) == 2 && a.packed && a.Hout % 8 == 0) return 2;
   return a.Hout % 16 == 0 ? 4 : 0;
 }
 
 bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu) {
-  const char* env = getenv("EOVAE_C8_W4");   // "0": never, "1": whenever the shape allows (default: when it pays)
-  if (env && env[0] == '0') return false;
+  const int mode = eovae_opt(EOVAE_OPT_C8_W4);   // 0: never, 1: whenever the shape allows, -1 (default): when it pays
+  if (mode == 0) return false;
   if (subpix != 0 || a.mode != MODE_NORMAL) return false;
   if (a.Cout % 128 || a.Cin % 32 || a.Wout % 32 || a.Hin != a.Hout || a.Win != a.Wout) return false;
   const int ni = w4_rows_per_wave(a, n_cu);
   if (!ni) return false;
   const long long tiles = (long long)a.N * (a.Hout / (4 * ni)) * (a.Wout / 32) * (a.Cout / 128);
-  if (env && env[0] == '1') return tiles >= 1;
+  if (mode == 1) return tiles >= 1;
   return tiles >= (ni == 2 ? 4LL : 2LL) * n_cu;   // fewer tiles than two per block leave CUs idle: the 8-wave kernel takes those
 }
 
@@ -635,10 +634,9 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   const long long sp_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
   a.xcd_remap = (a.ncob > 1 && sp_tiles % 8 == 0) ? 1 : 0;
   a.ntiles = (int)(sp_tiles * a.ncob);
-  const char* sg = getenv("EOVAE_C8_W4_STAGGER");
-  a.stagger = sg ? atoi(sg) : 0;
-  const char* sk = getenv("EOVAE_C8_W4_SKEW");   // experiment hook: units of 4096 cycles; default = half a tile
-  a.skew = ni == 2 ? (sk ? atoi(sk) : (a.nchunk * 7 + 2) / 5) : 0;
+  a.stagger = eovae_opt(EOVAE_OPT_C8_W4_STAGGER);
+  const int sk = eovae_opt(EOVAE_OPT_C8_W4_SKEW);   // experiment hook: units of 4096 cycles; -1 = half a tile
+  a.skew = ni == 2 ? (sk >= 0 ? sk : (a.nchunk * 7 + 2) / 5) : 0;
   const int nblk = ni == 2 ? 2 * n_cu : n_cu;
   const dim3 grid((unsigned)(a.ntiles < nblk ? a.ntiles : nblk)), blk(256);
   if (ni == 2) {

@@ -432,8 +432,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
 // LDS-DMA issue and addressing 200, fragment reads 176, SGPR-spill lane moves 130, waits 86, dY loads + 64-bit
 // addressing 90, tile decode 80 ...), while the 8-wave kernel spreads the same staging over two waves per SIMD.
 bool eovae_c8_wgrad_w4_eligible(const WgCArgs& a) {
-  const char* env = getenv("EOVAE_C8_WGRAD_W4");
-  if (!env || env[0] != '1') return false;
+  if (eovae_opt(EOVAE_OPT_C8_WGRAD_W4) != 1) return false;
   if (a.subpix != 0 || a.mode != MODE_NORMAL || !a.xpacked) return false;
   if (a.Cout % 128 || a.Cin % 64 || a.Wout % 32 || a.Hout % 2 || a.Hin != a.Hout || a.Win != a.Wout) return false;
   return a.split >= 1 && a.ntiles >= a.split;

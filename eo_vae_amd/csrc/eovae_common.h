@@ -11,7 +11,15 @@
 
 // run-time switches (api.cpp): value of option `id`, initialised once from its environment variable, changed only by
 // eovae_set_option
-enum { EOVAE_OPT_WGRAD_ROWS = 0, EOVAE_OPT_COUNT };
+enum {
+  EOVAE_OPT_WGRAD_ROWS = 0,   // row-streaming weight gradient (1)
+  EOVAE_OPT_C8_W4,            // one-wave-per-SIMD conv kernel: -1 when it pays (default), 0 never, 1 whenever the shape allows
+  EOVAE_OPT_C8_W4_NI,         // rows per wave of that kernel: 4 (default) or 2 (experiment, record inputs only)
+  EOVAE_OPT_C8_W4_STAGGER,    // experiment: start delay per block group, units of 1024 cycles (0)
+  EOVAE_OPT_C8_W4_SKEW,       // experiment (NI = 2): start delay of a CU's second block, units of 4096 cycles; -1 = half a tile
+  EOVAE_OPT_C8_WGRAD_W4,      // parked one-wave weight gradient (0)
+  EOVAE_OPT_COUNT
+};
 int eovae_opt(int id);
 
 // thread-local last-error text, exported through eovae_last_error()

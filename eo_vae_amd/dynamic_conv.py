@@ -62,6 +62,12 @@ def prefer_rocblas_for_generator():
         return _BLAS_STATE['backend']
     backend = 'default'
     if os.environ.get('EOVAE_GENERATOR_BLAS', 'rocblas') == 'rocblas':
+        if torch.cuda.is_available() and torch.cuda.is_initialized() and os.environ.get('DISABLE_ADDMM_CUDA_LT') != '1':
+            # PyTorch reads DISABLE_ADDMM_CUDA_LT at its first addmm: called this late, the bias-fused GEMMs may stay on
+            # hipBLASLt (2-4 x slower per call at 132 rows, results differ by up to ~2e-4) -- said out loud, not guessed
+            import warnings
+            warnings.warn('prefer_rocblas_for_generator() called after CUDA was initialised: set DISABLE_ADDMM_CUDA_LT=1 in '
+                          'the environment (or call it before the first GEMM) for every hyper-network GEMM to use rocBLAS')
         os.environ.setdefault('DISABLE_ADDMM_CUDA_LT', '1')       # addmm + bias would still go to hipBLASLt (read once by
         try:                                                      # PyTorch: effective when set before the first addmm)
             import warnings

@@ -30,8 +30,11 @@ int eovae_abi_version(void);
 const char* eovae_target_arch(void); /* "gfx950" */
 /* Run-time switches for A/B runs and tests (kernel selection only -- never arithmetic).  Each option starts from its
  * environment variable, read once; afterwards only eovae_set_option changes it.  Returns 0 / the value, or a negative
- * status for an unknown name.  Options: "c8_wgrad_rows" (EOVAE_C8_WGRAD_ROWS, default 1): plain 3x3 weight gradients
- * with record input run the row-streaming kernel instead of the tile kernel. */
+ * status for an unknown name.  Options (environment variable, default):
+ *   "c8_wgrad_rows" (EOVAE_C8_WGRAD_ROWS, 1)  plain 3x3 weight gradients with record input run the row-streaming kernel
+ *   "c8_w4"         (EOVAE_C8_W4, -1)         one-wave-per-SIMD conv kernel: -1 where it pays, 0 never, 1 wherever the shape allows
+ *   "c8_w4_ni" (4), "c8_w4_stagger" (0), "c8_w4_skew" (-1)   experiment hooks of that kernel (csrc/conv_f16c8_w4.hip)
+ *   "c8_wgrad_w4"   (EOVAE_C8_WGRAD_W4, 0)    the parked one-wave weight gradient (csrc/conv_f16c8_wgrad_w4.hip) */
 /* Diagnostic (csrc/diag.hip): the shader clock the chip holds under a dense f16-MFMA load.  Every workgroup (512 threads,
  * one per CU) runs `iters` rounds of 16 MFMAs per wave and writes {shader cycles, 100-MHz wall ticks} of its loop to
  * out[2 b], out[2 b + 1]: clock = cycles / ticks x 0.1 GHz.  Touches no product tensor. */

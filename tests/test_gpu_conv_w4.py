@@ -1,8 +1,8 @@
 """GPU: the one-wave-per-SIMD f16c8 convolution kernel (csrc/conv_f16c8_w4.hip: 4 waves, 4 x 4 blocks of 32 x 32 per
 wave, 16-row tiles) against the 8-wave kernel it relieves (same operands, same products: only the fp32 summation
 order differs) and against plain fp32 torch on the CPU.  EOVAE_C8_W4=1 routes every layer that fits the kernel's
-tile shape to it, =0 none (the library reads the variable per call)."""
-import os
+tile shape to it, =0 none; since round 4 the switches are library options (eovae_set_option: read from the environment once,
+then only changed through the ABI -- no os.environ mutation under a running launch)."""
 
 import pytest
 import torch
@@ -20,21 +20,20 @@ def rel(a, b):
 def f16c8_mode(request):
     """Both tile shapes of the kernel: 4 rows per wave (16-row tiles, one block per CU) and 2 rows per wave (8-row
     tiles, two skewed blocks per CU)."""
-    from eo_vae_amd import ops
+    from eo_vae_amd import lib as L, ops
+    lib = L.load()
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
-    env = {k: os.environ.get(k) for k in ('EOVAE_C8_W4', 'EOVAE_C8_W4_NI')}
-    os.environ['EOVAE_C8_W4_NI'] = request.param
+    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_w4_ni')}
+    L.check(lib.eovae_set_option(b'c8_w4_ni', int(request.param)), 'set_option')
     yield
     ops.CONV_PRECISION = old
-    for k, v in env.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    for k, v in keep.items():
+        lib.eovae_set_option(k, v)
 
 
 def run(fn, w4):
-    os.environ['EOVAE_C8_W4'] = '1' if w4 else '0'
+    from eo_vae_amd import lib as L
+    L.check(L.load().eovae_set_option(b'c8_w4', 1 if w4 else 0), 'set_option')
     out = fn()
     torch.cuda.synchronize()
     return out

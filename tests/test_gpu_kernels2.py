@@ -1,5 +1,7 @@
 """GPU: attention, latent glue, losses, optimiser and statistics kernels against fp32 PyTorch-CPU
 statements / the oracle / golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -112,6 +114,41 @@ def test_dynamic_convs_against_golden(golden):
             assert rel(dout(T(g[f'{mod}.h']).cuda(), wvs), g[f'{mod}.y_out']) < 1e-4
             w, b = din.get_distillation_weight(wvs)
             assert rel(w, g[f'{mod}.w_in']) < 1e-4 and rel(b, g[f'{mod}.b_in']) < 1e-4
+
+
+def test_dynamic_convs_with_the_default_blas_library():
+    """a host application that embeds the model without calling prefer_rocblas_for_generator() (or with
+    EOVAE_GENERATOR_BLAS=keep) runs the hyper-networks on PyTorch's default GEMM library (hipBLASLt).  Covered here in a
+    fresh process (the BLAS preference is process-wide and this session has already chosen rocBLAS): generated kernels
+    against the reference fixture at a bar that holds for either library (observed up to 1.8e-4 with hipBLASLt)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from oracle import eo_vae_cpu as O
+from eo_vae_amd.dynamic_conv import DynamicConv, generator_blas_backend, prefer_rocblas_for_generator
+assert prefer_rocblas_for_generator() == 'default' and generator_blas_backend() == 'default'
+g = dict(np.load('tests/golden/op_dynconv.npz'))
+ref = O.DynamicConv(wv_planes=256, embed_dim=128, num_layers=4)
+O.det_fill(ref, seed=14)
+d = DynamicConv(wv_planes=256, inter_dim=128, embed_dim=128, num_layers=4)
+d.load_state_dict(ref.state_dict())
+d.cuda().eval()
+worst = 0.0
+for mod, wl in O.WAVELENGTHS.items():
+    with torch.no_grad():
+        w, b = d.get_distillation_weight(torch.tensor(wl).cuda())
+    e = float((w.cpu() - torch.from_numpy(g[mod + '.w_in'])).abs().max() / np.abs(g[mod + '.w_in']).max())
+    worst = max(worst, e)
+print('WORST', worst)
+assert worst < 5e-4, worst
+"""
+    env = dict(os.environ, EOVAE_GENERATOR_BLAS='keep')
+    env.pop('DISABLE_ADDMM_CUDA_LT', None)
+    r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_posterior_against_golden(golden):

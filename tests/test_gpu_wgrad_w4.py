@@ -1,7 +1,7 @@
 """GPU: the one-wave-per-SIMD f16c8 weight-gradient kernel (csrc/conv_f16c8_wgrad_w4.hip) against the 8-wave kernel
 (same operands and products, other summation order and atomic order) and plain fp32 torch on the CPU.
-EOVAE_C8_WGRAD_W4=0 keeps every layer on the 8-wave kernel (the library reads the variable per call)."""
-import os
+The kernel is PARKED (slower than the 8-wave kernels): it only serves the atomic-accumulator path
+(ops.WGRAD_DIRECT = False) with the library option c8_wgrad_w4 = 1, which is how this file reaches it."""
 
 import pytest
 import torch
@@ -17,19 +17,19 @@ def rel(a, b):
 
 @pytest.fixture(autouse=True)
 def f16c8_mode():
-    from eo_vae_amd import ops
+    from eo_vae_amd import lib as L, ops
+    lib = L.load()
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
-    env = os.environ.get('EOVAE_C8_WGRAD_W4')
+    direct, ops.WGRAD_DIRECT = ops.WGRAD_DIRECT, False       # the atomic-accumulator path: the only one the parked kernel serves
+    keep = lib.eovae_get_option(b'c8_wgrad_w4')
     yield
-    ops.CONV_PRECISION = old
-    if env is None:
-        os.environ.pop('EOVAE_C8_WGRAD_W4', None)
-    else:
-        os.environ['EOVAE_C8_WGRAD_W4'] = env
+    ops.CONV_PRECISION, ops.WGRAD_DIRECT = old, direct
+    lib.eovae_set_option(b'c8_wgrad_w4', keep)
 
 
 def run(fn, w4):
-    os.environ['EOVAE_C8_WGRAD_W4'] = '1' if w4 else '0'
+    from eo_vae_amd import lib as L
+    L.check(L.load().eovae_set_option(b'c8_wgrad_w4', 1 if w4 else 0), 'set_option')
     out = fn()
     torch.cuda.synchronize()
     return out

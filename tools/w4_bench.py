@@ -1,5 +1,5 @@
 """A/B of the two f16c8 forward / data-gradient kernels at the real layer shapes (B=16), interleaved rounds in ONE
-process (rule 24): EOVAE_C8_W4=0 -> conv_f16c8.hip (8 waves, 2x2 blocks), =1 -> conv_f16c8_w4.hip (4 waves, 4x4 blocks).
+process (rule 24): library option c8_w4 = 0 -> conv_f16c8.hip (8 waves, 2x2 blocks), =1 -> conv_f16c8_w4.hip (4 waves, 4x4 blocks).
     python tools/w4_bench.py            fp32 input and record input, per layer: ms and algorithmic TFLOP/s"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,7 +41,7 @@ for cin, cout, hw in shapes:
     for rnd in range(3):
         for k, f in cases.items():
             for v in '01':
-                os.environ['EOVAE_C8_W4'] = v
+                lib.eovae_set_option(b'c8_w4', int(v))
                 best[(k, v)] = min(best[(k, v)], timeit(f))
     for k in cases:
         t0, t1 = best[(k, '0')], best[(k, '1')]

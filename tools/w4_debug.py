@@ -8,8 +8,9 @@ g = torch.Generator().manual_seed(1)
 x = torch.randn(n, cin, h, w, generator=g).cuda()
 wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
 def run(v, ni):
-    os.environ['EOVAE_C8_W4'] = v
-    os.environ['EOVAE_C8_W4_NI'] = ni
+    from eo_vae_amd import lib as _L
+    _L.load().eovae_set_option(b'c8_w4', int(v))
+    _L.load().eovae_set_option(b'c8_w4_ni', int(ni))
     with torch.no_grad():
         y = ops.conv2d(x, wt, None, None, 'normal')
     torch.cuda.synchronize()
