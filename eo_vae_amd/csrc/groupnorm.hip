@@ -763,12 +763,14 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
 }
 
 // host-side state of the one-pass backward's hand-off protocol (see eovae_gn_silu_bwd)
-constexpr int GN_MAX_DEV = 64, GN_MAX_CTL = 256;
+constexpr int GN_MAX_DEV = 64, GN_MAX_CTL = 64;
 struct GnCtl { int dev; hipStream_t st; unsigned* block; };
 std::mutex g_gn_mu;
 unsigned long long g_gn_nonce = 0, g_gn_calls = 0;
-GnCtl g_gn_ctl[GN_MAX_CTL];
+GnCtl g_gn_ctl[GN_MAX_DEV * GN_MAX_CTL];
 int g_gn_nctl = 0;
+unsigned* g_gn_pool[GN_MAX_DEV] = {nullptr};   // GN_MAX_CTL blocks of 256 bytes per device, zeroed at allocation
+int g_gn_used[GN_MAX_DEV] = {0};
 unsigned long long* g_gn_sticky_host[GN_MAX_DEV] = {nullptr};
 unsigned long long* g_gn_sticky_dev[GN_MAX_DEV] = {nullptr};
 
@@ -983,6 +985,25 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
         g_gn_nonce |= 1;
       }
       z = g_gn_nonce + 0x9E3779B97F4A7C15ull * ++g_gn_calls;
+      // control blocks come from a per-device pool that is allocated and zeroed ONCE (first call on the device, which must
+      // not sit inside a stream capture); handing a block to a new stream -- a graph capture runs on a stream of its own --
+      // then needs no allocation and no memset.  A pool that is used up recycles its oldest assignment.
+      if (!g_gn_pool[dev]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+          (void)hipGetLastError();
+          eovae_set_error("gn_silu_bwd: the first one-pass backward on a device allocates its control blocks and cannot run "
+                          "inside a stream capture (call it once eagerly first)");
+          return EOVAE_ERR_UNSUPPORTED;
+        }
+        unsigned* pool = nullptr;
+        if (hipMalloc((void**)&pool, (size_t)GN_MAX_CTL * 256) != hipSuccess ||
+            hipMemset(pool, 0, (size_t)GN_MAX_CTL * 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+          eovae_set_error("gn_silu_bwd: cannot allocate the ticket counters");
+          return EOVAE_ERR_LAUNCH;
+        }
+        g_gn_pool[dev] = pool;
+      }
       if (!g_gn_sticky_host[dev]) {
         void* h = nullptr;
         void* d = nullptr;
@@ -998,18 +1019,15 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
       for (int i = 0; i < g_gn_nctl; ++i)
         if (g_gn_ctl[i].dev == dev && g_gn_ctl[i].st == st) ticket_block = g_gn_ctl[i].block;
       if (!ticket_block) {
-        if (g_gn_nctl >= GN_MAX_CTL) {
-          eovae_set_error("gn_silu_bwd: more than %d (device, stream) pairs use the one-pass backward", GN_MAX_CTL);
-          return EOVAE_ERR_UNSUPPORTED;
-        }
-        if (hipMalloc((void**)&ticket_block, 256) != hipSuccess || hipMemsetAsync(ticket_block, 0, 256, st) != hipSuccess) {
-          eovae_set_error("gn_silu_bwd: cannot allocate the ticket counter");
-          return EOVAE_ERR_LAUNCH;
-        }
-        g_gn_ctl[g_gn_nctl].dev = dev;
-        g_gn_ctl[g_gn_nctl].st = st;
-        g_gn_ctl[g_gn_nctl].block = ticket_block;
-        ++g_gn_nctl;
+        int slot = g_gn_used[dev]++ % GN_MAX_CTL;               // (a recycled block is in its rest state: every finalize resets it)
+        ticket_block = g_gn_pool[dev] + (size_t)slot * 64;
+        int e = -1;
+        for (int i = 0; i < g_gn_nctl; ++i)
+          if (g_gn_ctl[i].dev == dev && g_gn_ctl[i].block == ticket_block) e = i;   // the assignment being recycled
+        if (e < 0) e = g_gn_nctl < GN_MAX_DEV * GN_MAX_CTL ? g_gn_nctl++ : 0;
+        g_gn_ctl[e].dev = dev;
+        g_gn_ctl[e].st = st;
+        g_gn_ctl[e].block = ticket_block;
       }
     }
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
