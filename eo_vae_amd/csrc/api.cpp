@@ -68,6 +68,6 @@ int eovae_get_option(const char* name) {
   eovae_set_error("eovae_get_option: unknown option '%s'", name ? name : "(null)");
   return EOVAE_ERR_ARG;
 }
-int eovae_abi_version(void) { return 9; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option
+int eovae_abi_version(void) { return 10; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option; 10: eovae_gen_* (weight generators)
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

@@ -1567,15 +1567,76 @@ __global__ __launch_bounds__(256) void pack_multi_amax_kernel(const PackDesc* __
     pack_parts_of(d)[blockIdx.x] = (m < 3.0e38f) ? m : 0.f;
   }
 }
+// Both orientations of a layer from ONE coalesced read of its weights.  The per-element gather of pack_f16c8_body reads
+// w[co][ci][tap] at a 36-byte stride per tap pass (9 passes over the tensor) and, for the flipped image, one cache line per
+// lane: 0.94 ms per step for the 84 M weights of the full model (profiles/r04w_step_timeline.txt), 0.7 TB/s.  Here a block
+// stages a 32 co x 32 ci x 9 tap sub-block in LDS (32 contiguous 1,152-byte rows) and writes the 9 x 2 tile pieces it
+// owns: 512-byte runs in the packed images.  Same arithmetic per element as pack_f16c8_body (bit-identical output).
+constexpr int PKB = 32, PKP = PKB * 9 + 1;
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ descs, float scale) {
-  const PackDesc d = descs[blockIdx.y >> 1];
-  const int flip = blockIdx.y & 1;
-  const int k = flip ? d.Cout : d.Cin, m = flip ? d.Cin : d.Cout;
-  const int nchunk = cdiv_d(k, 32), ncob = cdiv_d(m, 128);
-  unsigned char* base = flip ? d.wp_bwd : d.wp_fwd;
-  unsigned* hdr = reinterpret_cast<unsigned*>(base + (size_t)9 * nchunk * ncob * 16384);
-  pack_f16c8_body(d.w, base, d.Cout, d.Cin, nchunk, ncob, flip, scale, pack_parts_of(d), PACK_MULTI_PARTS, hdr, blockIdx.x,
-                  gridDim.x);
+  __shared__ float tile[PKB * PKP];
+  __shared__ float wmax_s[4];
+  const PackDesc d = descs[blockIdx.y];
+  const int tid = threadIdx.x;
+  {
+    float m = tid < PACK_MULTI_PARTS ? pack_parts_of(d)[tid] : 0.f;
+    m = wave_max(m);
+    if ((tid & 63) == 0) wmax_s[tid >> 6] = m;
+    __syncthreads();
+  }
+  const float wmax = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
+  // orientation 0 (forward): k = ci, m = co;  1 (data gradient): k = co, m = ci, taps reversed
+  const int nchunk0 = cdiv_d(d.Cin, 32), ncob0 = cdiv_d(d.Cout, 128);
+  const int nchunk1 = cdiv_d(d.Cout, 32), ncob1 = cdiv_d(d.Cin, 128);
+  if (blockIdx.x == 0 && tid == 0) {
+    const unsigned wbits = __builtin_bit_cast(unsigned, wmax);
+    *reinterpret_cast<unsigned*>(d.wp_fwd + (size_t)9 * nchunk0 * ncob0 * 16384) = wbits;
+    *reinterpret_cast<unsigned*>(d.wp_bwd + (size_t)9 * nchunk1 * ncob1 * 16384) = wbits;
+  }
+  const float amax = wmax * fabsf(scale);
+  const int e1 = amax > 0.f ? 7 - expo_of_bits(__builtin_bit_cast(unsigned, amax)) : 0;
+  const float s_hi = pow2f(e1), s_lo = pow2f(e1 + 12);
+  const int cobk = ncob0 * 4, cibk = ncob1 * 4;          // 32-blocks over the 128-padded extents
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  for (int blk = blockIdx.x; blk < cobk * cibk; blk += gridDim.x) {
+    const int co0 = (blk / cibk) * PKB, ci0 = (blk % cibk) * PKB;
+    const bool fwd = ci0 < nchunk0 * 32, bwd = co0 < nchunk1 * 32;
+    if (!fwd && !bwd) continue;
+    const int ncol = max(0, min(PKB, d.Cin - ci0)) * 9;
+    __syncthreads();                                     // the previous sub-block has been read out
+    for (int e = tid; e < PKB * PKB * 9; e += 256) {
+      const int r = e / (PKB * 9), c = e % (PKB * 9);
+      tile[r * PKP + c] = (co0 + r < d.Cout && c < ncol) ? d.w[((size_t)(co0 + r) * d.Cin + ci0) * 9 + c] * scale : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < 18; ++it) {
+      const int o = it / 9, tap = it % 9;
+      if (o == 0 ? !fwd : !bwd) continue;
+      const int k4 = tid & 7, ml = tid >> 3;
+      float v[4], lo[4];
+      f16x4 hh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kl = k4 * 4 + j;
+        v[j] = o == 0 ? tile[ml * PKP + kl * 9 + tap] : tile[kl * PKP + ml * 9 + (8 - tap)];
+        hh[j] = (_Float16)v[j];
+        lo[j] = v[j] - (float)hh[j];
+      }
+      int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * s_hi, v[1] * s_hi, 0, false);
+      w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * s_hi, v[3] * s_hi, w_hi, true);
+      int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0] * s_lo, lo[1] * s_lo, 0, false);
+      w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2] * s_lo, lo[3] * s_lo, w_lo, true);
+      const int k0 = o == 0 ? ci0 : co0, mm = (o == 0 ? co0 : ci0) + ml;
+      const int nchunk = o == 0 ? nchunk0 : nchunk1, ncob = o == 0 ? ncob0 : ncob1;
+      unsigned char* t = (o == 0 ? d.wp_fwd : d.wp_bwd) + ((size_t)(tap * nchunk + (k0 >> 5)) * ncob + (mm >> 7)) * 16384;
+      const int m_ = mm & 127, kk = k4 * 4;
+      *reinterpret_cast<f16x4*>(t + (kk >> 3) * 2048 + m_ * 16 + (kk & 7) * 2) = hh;
+      unsigned char* p8 = t + 8192 + ((kk >> 4) * 128 + m_) * 16 + (kk & 15);
+      *reinterpret_cast<int*>(p8) = w_hi;
+      *reinterpret_cast<int*>(p8 + 2 * 128 * 16) = w_lo;
+    }
+  }
 }
 
 }  // namespace
@@ -1675,7 +1736,7 @@ int eovae_conv3x3_f16c8_pack_multi(const void* descs, int n, float scale, void* 
   static_assert(sizeof(PackDesc) == 32, "PackDesc layout is part of the ABI");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(pack_multi_amax_kernel, dim3(PACK_MULTI_PARTS, n), dim3(256), 0, st, (const PackDesc*)descs);
-  hipLaunchKernelGGL(pack_multi_kernel, dim3(96, 2 * n), dim3(256), 0, st, (const PackDesc*)descs, scale);
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(64, n), dim3(256), 0, st, (const PackDesc*)descs, scale);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack_multi");
   return EOVAE_OK;
 }

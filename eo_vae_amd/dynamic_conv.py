@@ -14,7 +14,7 @@ import torch.nn.functional as F
 import torch.nn.init as init
 from torch.nn.attention import SDPBackend, sdpa_kernel
 
-from . import ops
+from . import generator_ops, ops
 
 
 def get_1d_sincos_pos_embed_from_grid_torch(embed_dim: int, pos: torch.Tensor) -> torch.Tensor:
@@ -35,6 +35,9 @@ class FCResLayer(nn.Module):  # :336-366
         self.w2 = nn.Linear(linear_size, linear_size)
 
     def forward(self, x):
+        if GENERATOR_KERNELS:
+            lin = generator_ops.linear
+            return x + F.relu(lin(F.relu(lin(x, self.w1.weight, self.w1.bias)), self.w2.weight, self.w2.bias))
         return x + F.relu(self.w2(F.relu(self.w1(x))))
 
 
@@ -44,6 +47,10 @@ class FCResLayer(nn.Module):  # :336-366
 # copies; the same post-norm layer written out on the same parameters needs 13 (one in_proj GEMM, a scaled
 # batched QK^T, softmax, PV, one head-merge copy, out_proj, add, LayerNorm, FFN GEMM + GELU + GEMM, add, LayerNorm).
 FAST_GENERATOR = os.environ.get('EOVAE_FAST_GENERATOR', '1') != '0'
+# Round 4: the layer and the Linear layers around it are HIP kernels of this product (csrc/generator.hip through
+# generator_ops: 9 launches per layer forward, ~22 backward, no BLAS library).  EOVAE_GENERATOR_KERNELS=0 keeps the
+# PyTorch-op formulation below for A/B timing and as the fp32 reference of tests/test_gpu_generator.py.
+GENERATOR_KERNELS = os.environ.get('EOVAE_GENERATOR_KERNELS', '1') != '0'
 _TIMING_ONLY_FREEZE = os.environ.get('EOVAE_TIMING_FREEZE_GENERATORS', '0') == '1'
 DEAD_ROW_ELIMINATION = os.environ.get('EOVAE_GENERATOR_DEAD_ROWS', '1') != '0'   # 0: the last layer computes all rows
 
@@ -154,16 +161,20 @@ class TransformerWeightGenerator(nn.Module):  # :62-130
         enc = self.transformer_encoder
         if FAST_GENERATOR and enc.norm is None and all(_layer_is_plain(lyr) for lyr in enc.layers):
             n = len(enc.layers)
+            layer_fn = generator_ops.encoder_layer if GENERATOR_KERNELS else _encoder_layer
             for i, lyr in enumerate(enc.layers):   # the last layer only computes the rows the generator reads
-                seq = _encoder_layer(lyr, seq, self.wt_num if (i == n - 1 and DEAD_ROW_ELIMINATION) else 0)
+                seq = layer_fn(lyr, seq, self.wt_num if (i == n - 1 and DEAD_ROW_ELIMINATION) else 0)
             if DEAD_ROW_ELIMINATION:
                 return seq                          # rows wt_num .. L - 1
             return seq[self.wt_num:]
         return enc(seq)[self.wt_num:]  # unbatched [L, d]
 
+    def _fc(self, lin, x):
+        return generator_ops.linear(x, lin.weight, lin.bias) if GENERATOR_KERNELS else lin(x)
+
     def forward(self, waves):
         out = self._tokens(waves)                   # [C + 1, d]: the wavelength rows and the bias row
-        return self.fc_weight(out[:-1] + waves), self.fc_bias(out[-1])
+        return self._fc(self.fc_weight, out[:-1] + waves), self._fc(self.fc_bias, out[-1])
 
 
 class TransformerWeightGenerator_decoder(TransformerWeightGenerator):  # :133-183
@@ -172,8 +183,8 @@ class TransformerWeightGenerator_decoder(TransformerWeightGenerator):  # :133-18
     def forward(self, waves):
         out = self._tokens(waves)
         wave_out = out[:-1]
-        bias = self.fc_bias(wave_out + self.bias_token.repeat(waves.shape[0], 1))
-        return self.fc_weight(wave_out + waves), bias
+        bias = self._fc(self.fc_bias, wave_out + self.bias_token.repeat(waves.shape[0], 1))
+        return self._fc(self.fc_weight, wave_out + waves), bias
 
 
 def _xavier_linear(m):

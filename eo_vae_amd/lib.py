@@ -64,6 +64,10 @@ SIGNATURES = {
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
     'eovae_softmax_bwd_rows': (_i, [_p, _p, _ll, _i, _p]),
+    'eovae_gen_gemm': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + [_ll] * 8 + [_f, _i, _i, _ll, _p]),
+    'eovae_gen_ln_fwd': (_i, [_p, _i, _ll, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    'eovae_gen_ln_bwd': (_i, [_p, _p, _i, _ll, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    'eovae_gen_colsum': (_i, [_p, _p, _i, _i, _ll, _p]),
     'eovae_gemm_bf16x3': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _i, _i, _i, _i, _ll, _ll, _p]),
     'eovae_attention_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     'eovae_attention_bwd': (_i, [_p] * 9 + [_i, _i, _i, _f, _i, _p]),
@@ -98,7 +102,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 9  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 10  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

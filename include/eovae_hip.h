@@ -248,6 +248,30 @@ int eovae_attention_bwd(const float* q, const float* k, const float* v, const fl
                         int T, float scale, int precision, void* stream);
 
 /* ----------------------------------------------------------------------------------------
+ * Weight generators of the dynamic convolutions (csrc/generator.hip): the post-norm transformer encoder layer
+ *   nn.TransformerEncoderLayer(d 256, 4 heads, FFN 2048, GELU, dropout 0)   modules/dynamic_conv.py:86-101, 152-167
+ * and the Linear layers around it (:111-113, 336-366) as small exact-fp32 kernels over the [<= 160, 256] token matrix.
+ *   gen_gemm   C[b](m,n) = epi(alpha * sum_k A[b](m,k) B[b](n,k)); element strides; C rows scm apart, columns contiguous
+ *              epi 0: + bias[n] (nullable) | 1: + bias, pre-activation -> aux_out (layout of C), GELU -> C
+ *                  2: times GELU'(aux)     | 3: C += value
+ *              ksplit > 1: K slice s -> C + s * part_stride, no epilogue (folded by gen_ln_fwd / gen_ln_bwd)
+ *   gen_ln_fwd y = LayerNorm(sum_s parts[s] + bias + res) * gamma + beta; keeps xhat [rows][d] and rstd [rows]
+ *   gen_ln_bwd dx of it for dy_total = dy + sum_s parts[s] (written to dysum when nparts > 0); dgamma / dbeta when given
+ *   gen_colsum out[c] = sum_r x[r * ld + c]   (bias gradients)
+ * -------------------------------------------------------------------------------------- */
+int eovae_gen_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux, float* aux_out, int batch,
+                   int M, int N, int K, long long sam, long long sak, long long sbn, long long sbk, long long scm,
+                   long long batA, long long batB, long long batC, float alpha, int epi, int ksplit, long long part_stride,
+                   void* stream);
+int eovae_gen_ln_fwd(const float* parts, int nparts, long long part_stride, const float* bias, const float* res,
+                     const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int rows, int d, float eps,
+                     void* stream);
+int eovae_gen_ln_bwd(const float* dy, const float* parts, int nparts, long long part_stride, float* dysum, const float* xhat,
+                     const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, int rows, int d,
+                     void* stream);
+int eovae_gen_colsum(const float* x, float* out, int rows, int n, long long ld, void* stream);
+
+/* ----------------------------------------------------------------------------------------
  * Latent glue (csrc/latent.hip)
  *   posterior: DiagonalGaussianDistribution            distributions.py:28-32,44-46,64-67
  *   latent_bn: rearrange 2x2 unshuffle + nn.BatchNorm2d(4Z, affine=False)

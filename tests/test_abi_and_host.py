@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, s), f'{s} declared in include/eovae_hip.h but not exported'
     # the ctypes table mirrors the header one to one
     assert sorted(L.SIGNATURES) == syms
-    assert cdll.eovae_abi_version() == L.ABI_VERSION == 9
+    assert cdll.eovae_abi_version() == L.ABI_VERSION == 10
     cdll.eovae_target_arch.restype = ctypes.c_char_p
     assert cdll.eovae_target_arch() == b'gfx950'
 
@@ -169,12 +169,14 @@ def test_pixel_shuffle_helpers_match_einops():
     assert torch.equal(_pack2x2(z5), rearrange(z5, '... c (i pi) (j pj) -> ... (c pi pj) i j', pi=2, pj=2))
 
 
-def test_generator_cache_is_keyed_on_wavelength_values():
+def test_generator_cache_is_keyed_on_wavelength_values(monkeypatch):
     """alternating two same-length wavelength sets through FRESH tensors in eval /
     no_grad must never return the other set's kernels (a recycled address used to hit a stale entry),
     and the same tensor object passed again must hit without being recomputed."""
     import gc
+    from eo_vae_amd import dynamic_conv
     from eo_vae_amd.dynamic_conv import DynamicConv
+    monkeypatch.setattr(dynamic_conv, 'GENERATOR_KERNELS', False)   # host logic of the cache on CPU tensors (no HIP here)
     torch.manual_seed(3)
     m = DynamicConv(wv_planes=64, embed_dim=32, num_layers=1).eval()
     sets = [[0.665, 0.56, 0.49], [0.842, 1.61, 2.19]]
