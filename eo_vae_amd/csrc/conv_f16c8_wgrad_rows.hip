@@ -121,6 +121,17 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// SP = 1: the "nearest x2 + 3x3" layer in sub-pixel form.  X is the LOW-res input (records), dY the 2x output gradient.
+// Output parity (py, px) of dY against X is a 2 x 2-tap weight gradient on the low-res grid:
+//     G[p][a][b] = sum dY[2 y + py][2 x + px] * X[y + a - 1 + py][x + b - 1 + px]          (a, b in {0, 1})
+// i.e. the plain walk over the parity image dY' with 4 of the 9 taps.  A block takes ONE parity (blockIdx: slab * 4 + p);
+// everything parity-specific is an address offset: dY' row R + 1 - py is what the plain kernel calls "row R + 1" (so the
+// two live ring positions are the same for both py), its pixels are the elements 0 and 2 of 16-byte loads that start px
+// floats in, and the X window starts px pixels to the right.  Per stage a wave runs 12 MFMAs (plain: 27) behind the same
+// staging work, so this form is issue-bound -- and still 1.7 x the tile kernel's sub-pixel mode, which also gathers X
+// by transposing reads from an fp32-converted halo.  The fold (wgrad_up_fold_kernel) sums the splits and maps
+// (parity, a, b) back to the nine taps of the layer's kernel.
+template <int SP>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char dys[NRING * DYSLOT];
   // FOUR arrays for the LDS-DMA targets (X row s + 3 is requested in stage s; row s + 1 is already read at the end of
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   const int ct = wave & 3, cih = wave >> 2;   // waves w and w + 4 share a SIMD: same co-tile, the two ci-tiles
   int slab, ysub;
   {   // XCD-aware block -> (slab, split slot) map, as wgrad3x3_f16c8_kernel
-    const int nslab = a.ncib * a.ncob_;
+    const int nslab = a.ncib * a.ncob_ * (SP ? 4 : 1);
     const int b = blockIdx.x;
     if (a.xcd_remap) {
       const int xcd = b & 7, q = b >> 3;
@@ -148,9 +159,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       ysub = b / nslab;
     }
   }
-  const int cib = uni(slab % a.ncib), cob = uni(slab / a.ncib);
-  const int H = a.Hout, W = a.Wout;
+  const int par = SP ? (slab & 3) : 0, py = par >> 1, px = par & 1;   // SP: slab = (cob * ncib + cib) * 4 + parity
+  const int slab_ = SP ? (slab >> 2) : slab;
+  const int cib = uni(slab_ % a.ncib), cob = uni(slab_ / a.ncib);
+  const int H = SP ? a.Hin : a.Hout, W = SP ? a.Win : a.Wout;   // the grid of X (and of dY')
   const unsigned plane = (unsigned)(H * W);
+  const unsigned dplane = SP ? 4u * plane : plane;               // a dY channel plane
 
   float dys_scale = 1.f, dyinv = 1.f;   // dy pre-scale: the power of two that puts its amax at 2^13..2^14
   if (a.dyamax) {
@@ -161,6 +175,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       dyinv = pow2f(e - 13);
     }
   }
+  if (SP && a.xamax) {   // the records were written from x * 2^(13 - e) (f16c8_records_kernel): undone with the result
+    const unsigned bits = *a.xamax;
+    if (bits) dyinv *= pow2f(expo_of_bits(bits) - 13);
+  }
   const int sc_a = 127 - 12, sc_b = 127;   // E8M0: both K blocks carry one operand scaled by 2^12
 
   // ---- the walk: units u = ysub, ysub + split, ... ; unit = (image n, strip tx, row segment seg) covers output rows
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   // the per-lane DMA offset change only when a unit opens.
   const int segrows = uni(H / a.nseg);
   const unsigned OOR = 0x80000000u;
-  const unsigned dyspan = (unsigned)a.Cout * plane * 4u, xspan = 8u * plane * 32u;
+  const unsigned dyspan = (unsigned)a.Cout * dplane * 4u, xspan = 8u * plane * 32u;
   struct Cursor {
     int R, r0, r1, live;
     unsigned xsoff, dsoff;     // byte offsets of X row R / of dY row R + 1 at the strip's first column (scalar offsets)
@@ -193,9 +211,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         c.r1 = c.r0 + segrows;
         c.R = c.r0 - 1;
         c.xsoff = (unsigned)uni((c.R * W) * 32);
-        c.dsoff = (unsigned)uni((c.r0 * W + x0) * 4);
+        c.dsoff = SP ? (unsigned)uni(((2 * (c.r0 - py) + py) * 2 * W + 2 * x0 + px) * 4) : (unsigned)uni((c.r0 * W + x0) * 4);
         c.xbase = uni_ptr(reinterpret_cast<const char*>(a.x) + ((size_t)n * (a.Cin / 8) + (size_t)cib * 8) * plane * 32);
-        c.dbase = uni_ptr(a.dy + (size_t)n * a.Cout * plane);
+        c.dbase = uni_ptr(a.dy + (size_t)n * a.Cout * dplane);
         const unsigned ln = threadIdx.x & 63u;
         const int px = x0 - 1 + (int)ln;
         vx = (ln < 34u && (unsigned)px < (unsigned)W) ? ((unsigned)wave * plane + (unsigned)px) * 32u : OOR;
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     } else {
       ++c.R;
       c.xsoff += (unsigned)(W * 32);
-      c.dsoff += (unsigned)(W * 4);
+      c.dsoff += (unsigned)((SP ? 4 : 1) * W * 4);
     }
   };
   int nst;   // stages of this block
@@ -220,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   // sets: the row of stage s + 2 is requested in stage s, the row of stage s + 1 is converted between the MFMAs of stage s.
   const int dq = tid & 3;
   const int dco = (EOVAE_ROWS_DBG & 1) ? (tid >> 2) : 8 * (tid >> 5) + ((tid >> 4) & 1) + (((tid >> 2) & 1) << 2) + (((tid >> 3) & 1) << 1);
-  const unsigned dvoff = ((unsigned)(cob * 128 + dco) * plane + 8u * (unsigned)dq) * 4u;
-  f32x4 dr[2][2];
+  const unsigned dvoff = ((unsigned)(cob * 128 + dco) * dplane + (SP ? 16u : 8u) * (unsigned)dq) * 4u;
+  f32x4 dr[2][SP ? 4 : 2];
   float dbs = 0.f;
   const bool do_db = a.db != nullptr && cib == 0;
   struct { const float* base; unsigned soff; int ok; } sv;   // the dY row of the cursor's stage, requested a stage later
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   auto save_dy = [&]() __attribute__((always_inline)) {
     sv.base = c.dbase;
     sv.soff = c.dsoff;
-    sv.ok = c.live & (c.R + 1 >= c.r0) & (c.R + 1 < c.r1);
+    sv.ok = c.live & (c.R + 1 - py >= c.r0) & (c.R + 1 - py < c.r1);
   };
   auto request_dy = [&](auto pc) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
@@ -239,13 +257,22 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         (EOVAE_ROWS_DBG & 8) ? uni_ptr(const_cast<float*>(sv.base)) : const_cast<float*>(sv.base), 0, nr, 0x00020000);
     dr[P][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, dvoff, so, 0));
     dr[P][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, dvoff + 16, so, 0));
+    if constexpr (SP != 0) {
+      dr[P][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, dvoff + 32, so, 0));
+      dr[P][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, dvoff + 48, so, 0));
+    }
   };
   const int dw16 = dco * P16 + dq * 16, dw8 = DY16 + dco * P8 + dq * 8;
   // conversion of one register set in two pieces placed between MFMA triples: pixels 0-3 | pixels 4-7, each stored at once
   // (8 + 4 + 4 bytes): nothing of a piece lives across an MFMA
   auto conv_piece = [&](auto pc, auto piece, unsigned char* slot) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value, I = decltype(piece)::value;
-    const f32x4 d = dr[P][I];
+    f32x4 d;
+    if constexpr (SP != 0) {   // every other hi-res pixel (the loads start px floats in)
+      d[0] = dr[P][2 * I][0]; d[1] = dr[P][2 * I][2]; d[2] = dr[P][2 * I + 1][0]; d[3] = dr[P][2 * I + 1][2];
+    } else {
+      d = dr[P][I];
+    }
     float v[4], lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = d[j] * dys_scale;
@@ -292,14 +319,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   const int a8off = DY16 + h * DY8 + (32 * ct + r) * P8;
   // B (X) f16 by ds_read_b64_tr_b16: lane 4q + p of group g supplies pixel q of its 4-pixel block, 8-byte chunk p & 1 of
   // octet 2 (g & 1) + (p >> 1) of the wave's ci-tile; k-half g >> 1
-  const int b16off = (4 * cih + 2 * (g & 1) + ((li & 3) >> 1)) * XP16 + (8 * (g >> 1) + (li >> 2)) * 16 + (li & 1) * 8;
+  const int b16off = (4 * cih + 2 * (g & 1) + ((li & 3) >> 1)) * XP16 + (8 * (g >> 1) + (li >> 2)) * 16 + (li & 1) * 8 + px * 16;
   // B fp8 by ds_read_b64_tr_b8: lane 2j + p supplies pixel j of its 8-pixel block, octet 2 (g & 1) + p; K block g >> 1:
   // block 0 = xh' (second 8 bytes of the pixel's 16), block 1 = xl'
-  const int b8off = X16 + cih * X8T + x8off(2 * (g & 1) + (li & 1)) + (li >> 1) * 16 + ((g >> 1) ? 0 : 8);
+  const int b8off = X16 + cih * X8T + x8off(2 * (g & 1) + (li & 1)) + (li >> 1) * 16 + ((g >> 1) ? 0 : 8) + px * 16;
 
-  f32x16 acc[9];
+  constexpr int NT = SP ? 4 : 9, NKX = SP ? 2 : 3;
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
   f16x8 A16[NRING][2];
@@ -365,20 +393,24 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off));
     A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off + 32));
     constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3;   // ring positions of ky = 1, 2 (ky = 0: K)
+    // accumulators: plain acc[3 ky + kx] (ky = 0: ring K, 1: R1, 2: R2); SP acc[2 a + b] (a = 0: ring K, 1: R1)
+    constexpr int T1 = SP ? 2 : 3;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < NKX; ++kx) {
       const f16x8 b0 = rtr16(xsl + b16off + kx * 16, xsl + b16off + (kx + 4) * 16);
       if (kx == KCNV) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3) -- two operations each
+        // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3) -- two operations each (SP: four for a dY row)
+        if constexpr (SP != 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma8(acc[3 + kx], A8[R1], b8, sc_a, sc_b);
+      mfma8(acc[T1 + kx], A8[R1], b8, sc_a, sc_b);
       if (kx == KREQ) {
         __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
         if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
       }
-      mfma8(acc[6 + kx], A8[R2], b8, sc_a, sc_b);
+      if constexpr (SP == 0) mfma8(acc[6 + kx], A8[R2], b8, sc_a, sc_b);
       if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) {
         request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
         save_dy();
@@ -389,21 +421,24 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       const f16x8 b1 = rtr16(xsl + b16off + (kx + 16) * 16, xsl + b16off + (kx + 20) * 16);
       if (kx == KCNV && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
       __builtin_amdgcn_sched_barrier(0);
-      mfma16(acc[3 + kx], A16[R1][0], b0);
-      mfma16(acc[6 + kx], A16[R2][0], b0);
+      mfma16(acc[T1 + kx], A16[R1][0], b0);
+      if constexpr (SP == 0) mfma16(acc[6 + kx], A16[R2][0], b0);
       mfma16(acc[kx], A16[K][0], b0);
       __builtin_amdgcn_sched_barrier(0);
-      if (kx < 2) b8 = rtr8(xsl + b8off + (kx + 1) * 16);
+      if (kx < NKX - 1) b8 = rtr8(xsl + b8off + (kx + 1) * 16);
       else b8 = rtr8(xslot_of(std::integral_constant<int, (Q + 1) % 4>{}) + b8off);   // the next stage's first B fragment
       __builtin_amdgcn_sched_barrier(0);
-      mfma16(acc[3 + kx], A16[R1][1], b1);
-      mfma16(acc[6 + kx], A16[R2][1], b1);
+      mfma16(acc[T1 + kx], A16[R1][1], b1);
+      if constexpr (SP == 0) mfma16(acc[6 + kx], A16[R2][1], b1);
       mfma16(acc[kx], A16[K][1], b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // X(s + 2) has landed when at most this stage's four operations are outstanding
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (!(EOVAE_ROWS_ABL & 4)) __syncthreads();
+    // X(s + 2) has landed when at most this stage's operations (dY(s + 2), X(s + 3)) are outstanding
+    if constexpr (SP != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // a RAW barrier behind the counted wait above: __syncthreads() carries a release fence = s_waitcnt vmcnt(0), which made
+    // every stage wait for the dY row and X row it had just requested for the stages after it
+    if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
   // ONE exit: with an exit behind every body (twelve exits) the compiler kept the cursor's scalars in vector registers and
@@ -437,14 +472,89 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     if (dq == 0) atomicAdd(&a.db[cob * 128 + dco], v);
   }
   // this block's partial tile [tap][128 co][64 ci], folded in a fixed order by wgrad_fold_kernel
-  float* pt = a.part + (((size_t)slab * a.split + ysub) * 9) * (128 * 64) + cih * 32 + r;
+  float* pt = a.part + (((size_t)slab * a.split + ysub) * NT) * (128 * 64) + cih * 32 + r;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int col = ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
       pt[(size_t)t * (128 * 64) + col * 64] = acc[t][q] * dyinv;
     }
+}
+
+
+// fp32 NCHW -> f16c8 operand records [N][C/8][HW][32 B] (the format gn_apply_packed_kernel writes, groupnorm.hip), for a
+// layer input that is not a GroupNorm output.  xamax (nullable): x is scaled by the power of two that puts its amax at
+// 2^13..2^14 first (the range guard of the fp32-input kernels); the consumer undoes it with its result.
+__global__ __launch_bounds__(256) void f16c8_records_kernel(const float* __restrict__ x, const unsigned* __restrict__ xamax,
+                                                            int* __restrict__ rec, int C, int HW, int pblocks) {
+  const int pb = blockIdx.x % pblocks, og = blockIdx.x / pblocks;   // og = n * C/8 + octet
+  const int p = pb * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float xs = 1.f;
+  if (xamax) {
+    const unsigned bits = *xamax;
+    if (bits) xs = pow2f(13 - expo_of_bits(bits));
+  }
+  float v[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = x[((size_t)og * 8 + j) * HW + p] * xs;
+  int pk[4];
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    int hh;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v[j]), "v"(v[j + 1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j]) : "v"(hh), "v"(v[j]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[j + 1]) : "v"(hh), "v"(v[j + 1]));
+    pk[j >> 1] = hh;
+  }
+  s16x2 l0 = {0, 0}, l1 = {0, 0};
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+  int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+  h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
+  int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
+  h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h1, true);
+  i32x4 a0, a1;
+  a0[0] = pk[0]; a0[1] = pk[1]; a0[2] = pk[2]; a0[3] = pk[3];
+  a1[0] = __builtin_bit_cast(int, l0); a1[1] = __builtin_bit_cast(int, l1); a1[2] = h0; a1[3] = h1;
+  i32x4* r = reinterpret_cast<i32x4*>(rec + ((size_t)og * HW + p) * 8);
+  r[0] = a0;
+  r[1] = a1;
+}
+
+// dW[co][ci][KY][KX] of the upsample layer from the parity tiles: part[(slab * 4 + p) * split + y][2 a + b][128][64];
+// tap (KY, KX) of the layer's kernel lands on (a, b) = (KY + py - 1 >= 1 ? .. ) of parity (py, px):
+//   py = 0: KY = 0 -> a = 0, KY = 1, 2 -> a = 1;   py = 1: KY = 0, 1 -> a = 0, KY = 2 -> a = 1   (same for KX, px, b).
+// Splits and parities are summed in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_up_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+                                                            int Cin, int ncib, int split) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)9 * Cout * Cin) return;
+  const int ci = (int)(i % Cin);
+  const int co = (int)((i / Cin) % Cout);
+  const int tap = (int)(i / ((size_t)Cin * Cout));
+  const int KY = tap / 3, KX = tap % 3;
+  const int slab = (co >> 7) * ncib + (ci >> 6);
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int py = p >> 1, px = p & 1;
+    const int a_ = py == 0 ? (KY == 0 ? 0 : 1) : (KY == 2 ? 1 : 0);
+    const int b_ = px == 0 ? (KX == 0 ? 0 : 1) : (KX == 2 ? 1 : 0);
+    const float* q = part + ((((size_t)slab * 4 + p) * split) * 4 + (2 * a_ + b_)) * (128 * 64) + (co & 127) * 64 + (ci & 63);
+    float s0 = 0.f, s1 = 0.f;
+    int y = 0;
+    for (; y + 1 < split; y += 2) {
+      s0 += q[(size_t)y * 4 * 128 * 64];
+      s1 += q[(size_t)(y + 1) * 4 * 128 * 64];
+    }
+    if (y < split) s0 += q[(size_t)y * 4 * 128 * 64];
+    s += s0 + s1;
+  }
+  dw[((size_t)co * Cin + ci) * 9 + tap] = s;
 }
 
 }  // namespace
@@ -464,5 +574,66 @@ void eovae_c8_wgrad_rows_launch(WgCArgs& a, hipStream_t st) {
   a.units = strips * nseg;
   if (a.split > a.units) a.split = a.units;
   a.xcd_remap = (a.ncib * a.ncob_ > 1 && a.split % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel, dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
+  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<0>, dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
 }
+
+// ---- the x2-upsample layer ("nearest x2 + 3x3", layers.py Upsample) in sub-pixel row-streaming form
+#ifndef EOVAE_WGRAD_BLOCKS
+#define EOVAE_WGRAD_BLOCKS 256   // one block per CU (conv_f16c8.hip)
+#endif
+static int up_rows_split(int Cin, int Cout) {
+  int split = EOVAE_WGRAD_BLOCKS / (4 * cdiv(Cin, 64) * cdiv(Cout, 128));
+  return split < 1 ? 1 : split;
+}
+
+extern "C" {
+
+int eovae_conv3x3_f16c8_wgrad_up_eligible(int N, int Cin, int H, int W, int Cout) {
+  return eovae_opt(EOVAE_OPT_WGRAD_ROWS) != 0 && N > 0 && Cout % 128 == 0 && Cin % 64 == 0 && W % 32 == 0 && H >= 1 &&
+         (long long)H * W * 32 * 8 < (1LL << 31) && (long long)Cout * H * W * 16 < (1LL << 32);
+}
+
+// scratch: the records of x (4 B per element) + one [4][128][64] fp32 tile per block
+size_t eovae_conv3x3_f16c8_wgrad_up_workspace(int N, int Cin, int H, int W, int Cout) {
+  if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const size_t rec = ((size_t)N * Cin * H * W * 4 + 255) / 256 * 256;
+  return rec + (size_t)4 * cdiv(Cin, 64) * cdiv(Cout, 128) * up_rows_split(Cin, Cout) * 4 * 128 * 64 * sizeof(float);
+}
+
+// Weight gradient of conv3x3(nearest_upsample_x2(x)): x fp32 [N][Cin][H][W], dy fp32 [N][Cout][2H][2W] -> dw[Cout][Cin][3][3]
+// (written).  dyamax / xamax: absmax bits of dy / x (xamax nullable = no pre-scale).  db (nullable) accumulates the bias
+// gradient into a pre-zeroed [Cout] (float atomics, as the other f16c8 weight-gradient entries).
+int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, float* db, const unsigned* dyamax,
+                                 const unsigned* xamax, int N, int Cin, int H, int W, int Cout, void* ws, void* stream) {
+  EOVAE_CHECK_ARG(x && dy && dw && ws, "conv3x3_f16c8_wgrad_up: null pointer");
+  EOVAE_CHECK_ARG(eovae_conv3x3_f16c8_wgrad_up_eligible(N, Cin, H, W, Cout), "conv3x3_f16c8_wgrad_up: shape N=%d Cin=%d %dx%d Cout=%d "
+                  "(Cout %% 128, Cin %% 64, W %% 32)", N, Cin, H, W, Cout);
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = H * W, pblocks = cdiv(HW, 256);
+  int* rec = (int*)ws;
+  hipLaunchKernelGGL(f16c8_records_kernel, dim3(N * (Cin / 8) * pblocks), dim3(256), 0, st, x, xamax, rec, Cin, HW, pblocks);
+  WgCArgs a;
+  a.x = reinterpret_cast<const float*>(rec); a.dy = dy; a.dwp = nullptr; a.db = db; a.dyamax = dyamax; a.xamax = xamax;
+  a.part = reinterpret_cast<float*>((char*)ws + ((size_t)N * Cin * HW * 4 + 255) / 256 * 256);
+  a.N = N; a.Cin = Cin; a.Hin = H; a.Win = W; a.Cout = Cout; a.Hout = 2 * H; a.Wout = 2 * W;
+  a.mode = MODE_NORMAL; a.subpix = 1; a.creal = 0; a.cpb = 1; a.xpacked = 1;
+  a.tiles_x = W / 32; a.tiles_y = H; a.ntiles = N * a.tiles_x * H;
+  a.ncib = Cin / 64; a.ncob_ = Cout / 128;
+  a.split = up_rows_split(Cin, Cout);
+  const int strips = N * a.tiles_x;
+  int nseg = 1;
+  while (strips * nseg < a.split && H % (2 * nseg) == 0 && H / (2 * nseg) >= 8) nseg *= 2;
+  a.nseg = nseg;
+  a.units = strips * nseg;
+  if (a.split > a.units) a.split = a.units;
+  const int nslab = 4 * a.ncib * a.ncob_;
+  a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<1>, dim3(nslab * a.split), dim3(512), 0, st, a);
+  const size_t total = (size_t)9 * Cout * Cin;
+  hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, a.ncib,
+                     a.split);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_up");
+  return EOVAE_OK;
+}
+
+}  // extern "C"

@@ -490,6 +490,9 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
 SUBPIX_UPSAMPLE = os.environ.get('EOVAE_SUBPIX', '1') != '0'
 
 
+UP_WGRAD_ROWS = True   # False: the tile kernel's sub-pixel mode (tests, A/B)
+
+
 def _subpix_ok(weight):
     return SUBPIX_UPSAMPLE and CONV_PRECISION != 'f32' and weight.shape[0] % 128 == 0
 
@@ -599,6 +602,21 @@ def up_conv_subpix_wgrad(x, dy, weight, db=None, xamax=None):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     lib = L.load()
+    if CONV_PRECISION == 'f16c8' and UP_WGRAD_ROWS and lib.eovae_conv3x3_f16c8_wgrad_up_eligible(n, cin, h, w, cout):
+        # row-streaming sub-pixel form: records of x once, four parity passes in one launch, a deterministic fold
+        if xamax is None:
+            xamax = range_amax(x)
+        timed = WGRAD3X3_TIMER is not None
+        if timed:
+            ev0, ev1 = WGRAD3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9, 4.0 * (x.numel() + dy.numel()))
+            ev0.record()
+        ws = workspace(lib.eovae_conv3x3_f16c8_wgrad_up_workspace(n, cin, h, w, cout), x.device)
+        dw = torch.empty_like(weight)
+        L.check(lib.eovae_conv3x3_f16c8_wgrad_up(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(amax_of(dy)), L.ptr(xamax),
+                                                 n, cin, h, w, cout, L.ptr(ws), L.stream()), 'eovae_conv3x3_f16c8_wgrad_up')
+        if timed:
+            ev1.record()
+        return dw
     dwp = torch.zeros(9 * 4 * cout * cin, dtype=torch.float32, device=x.device)
     _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, xamax=xamax)
     dw = torch.empty_like(weight)

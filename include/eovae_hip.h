@@ -133,6 +133,15 @@ int eovae_conv3x3_f16c8_wgrad_dw(const float* x, const float* dy, float* dw, flo
  * stream in front of Downsample / Upsample layers, layers.py:33-37, 47-50): x is pre-scaled by an exact power of two
  * like dy, so the f16c8 operands make no assumption about its range.  The forward entry takes the same pointer as
  * its `xamax` argument. */
+/* Weight gradient of the x2-upsample layer conv3x3(nearest_x2(x)) (layers.py Upsample) in sub-pixel ROW-STREAMING form
+ * (csrc/conv_f16c8_wgrad_rows.hip): x fp32 [N][Cin][H][W] is re-written once as operand records (scaled by xamax's power
+ * of two when given), each output parity of dy [N][Cout][2H][2W] is a 2x2-tap weight gradient on the low-res grid, a
+ * fold sums splits and parities in a fixed order into dw[Cout][Cin][3][3] (written).  db nullable (pre-zeroed, atomics).
+ * eligible: Cout % 128 == 0, Cin % 64 == 0, W % 32 == 0; ws >= eovae_conv3x3_f16c8_wgrad_up_workspace bytes. */
+int eovae_conv3x3_f16c8_wgrad_up_eligible(int N, int Cin, int H, int W, int Cout);
+size_t eovae_conv3x3_f16c8_wgrad_up_workspace(int N, int Cin, int H, int W, int Cout);
+int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, float* db, const unsigned* dyamax,
+                                 const unsigned* xamax, int N, int Cin, int H, int W, int Cout, void* ws, void* stream);
 /* xpacked = 1 (both entries above): x is not fp32 NCHW but the f16c8 OPERAND-RECORD tensor written by
  * eovae_gn_silu_fwd_packed: [N][C/8][H][W] records of 32 bytes = { 8 x f16 y | 8 x e5m2 (y - f16(y)) * 2^12 |
  * 8 x e5m2 y } for channels 8g..8g+7 -- N*C*H*W dwords, the size of the fp32 activation it replaces.  The

@@ -74,3 +74,49 @@ def test_rows_kernel_is_the_default_and_switchable():
     lib = L.load()
     assert lib.eovae_get_option(b'c8_wgrad_rows') == 1
     assert lib.eovae_set_option(b'no_such_option', 1) != 0 and b'unknown option' in lib.eovae_last_error()
+
+
+UP_SHAPES = [  # n, cin, cout, h, w (low-res input)
+    (2, 64, 128, 16, 32),     # one strip, one segment pair
+    (3, 128, 128, 12, 64),    # two strips, units % blocks != 0
+    (1, 192, 256, 20, 96),    # 3 ci slabs x 2 co slabs
+    (2, 512, 512, 8, 32),     # the model's 512-channel upsample at a small grid
+    (1, 64, 128, 9, 32),      # odd H
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', UP_SHAPES)
+def test_upsample_weight_gradient_rows(n, cin, cout, h, w):
+    """x2-upsample layer (layers.py Upsample: nearest x2 + 3x3): the sub-pixel row-streaming weight gradient against fp64
+    torch on the CPU and against the tile kernel's sub-pixel mode; bit-reproducible; the bias gradient rides along."""
+    import torch.nn.functional as F
+    from eo_vae_amd import ops
+    x = (hashed((n, cin, h, w), 321, 1.0) * 3.0).cuda()          # not a GroupNorm output: exercises the range pre-scale
+    wt = hashed((cout, cin, 3, 3), 322, 1.0 / (cin * 9) ** 0.5).cuda()
+    b = hashed((cout,), 323, 0.1).cuda()
+    gy = hashed((n, cout, 2 * h, 2 * w), 324, 1e-3).cuda()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = ops.UP_WGRAD_ROWS
+
+    def run(rows):
+        ops.UP_WGRAD_ROWS = rows
+        wg, bg = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        ops.conv2d(xin, wg, bg, None, 'up').backward(gy)
+        torch.cuda.synchronize()
+        return wg.grad.clone(), bg.grad.clone()
+    try:
+        d1, b1 = run(True)
+        d2, _ = run(True)
+        t1, bt = run(False)
+        assert torch.equal(d1, d2)
+        xc = F.interpolate(x.cpu().double(), scale_factor=2.0, mode='nearest')
+        wref = wt.cpu().double().requires_grad_(True)
+        bref = b.cpu().double().requires_grad_(True)
+        F.conv2d(xc, wref, bref, padding=1).backward(gy.cpu().double())
+        assert rel_err(d1, wref.grad) < 5e-5, rel_err(d1, wref.grad)
+        assert rel_err(t1, wref.grad) < 5e-5
+        assert rel_err(d1, t1) < 1e-5
+        assert rel_err(b1, bref.grad) < 2e-6 and rel_err(bt, bref.grad) < 2e-6
+    finally:
+        ops.CONV_PRECISION, ops.UP_WGRAD_ROWS = old, keep

@@ -42,3 +42,22 @@ for cin, cout, hw in shapes:
     t0, t1 = best[0], best[1]
     print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 wgrad (records, incl. fold): tile {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | rows {t1:7.3f} ms '
           f'{flops/t1/1e9:6.1f} TF | x{t0/t1:.3f} | rows vs tile {err:.1e}', flush=True)
+
+# x2-upsample layers (low-res shapes): tile kernel's sub-pixel mode vs the sub-pixel row-streaming form
+if os.environ.get('WGRAD_BENCH_UP', '1') != '0':
+    for cin, cout, hw in [(512, 512, 32), (512, 512, 64), (256, 256, 128)]:
+        x = torch.randn(B, cin, hw, hw, device='cuda') * 2
+        dy = torch.randn(B, cout, 2 * hw, 2 * hw, device='cuda') * 1e-4
+        w = torch.randn(cout, cin, 3, 3, device='cuda')
+        flops = 2.0 * B * 4 * hw * hw * cin * cout * 9
+        best, res = {False: 1e9, True: 1e9}, {}
+        for rnd in range(3):
+            for v in (False, True):
+                ops.UP_WGRAD_ROWS = v
+                run = lambda: ops.up_conv_subpix_wgrad(x, dy, w, torch.zeros(cout, device='cuda'))
+                best[v] = min(best[v], timeit(run, 5))
+                res[v] = run().clone()
+        err = ((res[True] - res[False]).abs().max() / res[False].abs().max()).item()
+        t0, t1 = best[False], best[True]
+        print(f'up {cin:4d}->{cout:4d} @{hw:3d}^2 -> {2*hw}^2 wgrad (incl. amax, records, fold): tile {t0:7.3f} ms {flops/t0/1e9:6.1f} TF alg | '
+              f'rows {t1:7.3f} ms {flops/t1/1e9:6.1f} TF alg ({flops*4/9/t1/1e9:5.1f} actual) | x{t0/t1:.3f} | rows vs tile {err:.1e}', flush=True)
