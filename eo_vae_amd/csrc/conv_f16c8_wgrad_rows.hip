@@ -73,6 +73,14 @@ constexpr int NRING = 3;
 // windows of 1 KiB at {0, 136, 8, 128} (mod 256), at least 1 KiB apart
 __device__ __forceinline__ constexpr int x8off(int o) { return o == 0 ? 0 : (o == 1 ? 1160 : (o == 2 ? 2312 : 3456)); }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -124,16 +132,18 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
 // SP = 1: the "nearest x2 + 3x3" layer in sub-pixel form.  X is the LOW-res input (records), dY the 2x output gradient.
 // Output parity (py, px) of dY against X is a 2 x 2-tap weight gradient on the low-res grid:
 //     G[p][a][b] = sum dY[2 y + py][2 x + px] * X[y + a - 1 + py][x + b - 1 + px]          (a, b in {0, 1})
-// i.e. the plain walk over the parity image dY' with 4 of the 9 taps.  A block takes ONE parity (blockIdx: slab * 4 + p);
-// everything parity-specific is an address offset: dY' row R + 1 - py is what the plain kernel calls "row R + 1" (so the
-// two live ring positions are the same for both py), its pixels are the elements 0 and 2 of 16-byte loads that start px
-// floats in, and the X window starts px pixels to the right.  Per stage a wave runs 12 MFMAs (plain: 27) behind the same
-// staging work, so this form is issue-bound -- and still 1.7 x the tile kernel's sub-pixel mode, which also gathers X
-// by transposing reads from an fp32-converted halo.  The fold (wgrad_up_fold_kernel) sums the splits and maps
-// (parity, a, b) back to the nine taps of the layer's kernel.
+// i.e. the plain walk over the parity image dY' with 4 of the 9 taps.  A block takes ONE ROW parity py (blockIdx: slab * 2
+// + py) and both column parities: it stages the hi-res row 2 (R + 1 - py) + py whole (64 pixels per strip, every loaded
+// byte used) and de-interleaves it into two pixel planes while converting.  dY' row R + 1 - py is what the plain kernel
+// calls "row R + 1", so the two live ring positions are the same for both py.  Waves = 4 co-tiles x 2 column parities;
+// a wave runs BOTH ci-tiles (8 accumulators: ci-tile x a x b), its X window starts px pixels to the right: 24 MFMAs per
+// stage and wave (plain 27; one parity per block was 12 behind the same staging work: issue-bound, 330-415 TFLOP/s of
+// actual MFMA work).  Two dY slots of two planes (a row's fragments are read once, at the start of the stage after its
+// conversion) keep the LDS at 157 KiB.  The fold (wgrad_up_fold_kernel) sums the splits and maps (parity, a, b) back to
+// the nine taps of the layer's kernel.
 template <int SP>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char dys[NRING * DYSLOT];
+  __shared__ __attribute__((aligned(16))) unsigned char dys[SP ? 4 * DYSLOT : NRING * DYSLOT];   // SP: 2 slots x 2 pixel planes
   // FOUR arrays for the LDS-DMA targets (X row s + 3 is requested in stage s; row s + 1 is already read at the end of
   // stage s): with one array and a computed slot offset the compiler cannot tell a DMA write from the fragment reads of
   // another slot and drains vmcnt(0) in front of every read (conv_f16c8_wgrad_w4.hip)
@@ -145,10 +155,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int g = lane >> 4, li = lane & 15;
-  const int ct = wave & 3, cih = wave >> 2;   // waves w and w + 4 share a SIMD: same co-tile, the two ci-tiles
+  // waves w and w + 4 share a SIMD: same co-tile, the two ci-tiles (SP: the two column parities, each wave both ci-tiles)
+  const int ct = wave & 3, cih = SP ? 0 : wave >> 2, pxw = SP ? wave >> 2 : 0;
   int slab, ysub;
   {   // XCD-aware block -> (slab, split slot) map, as wgrad3x3_f16c8_kernel
-    const int nslab = a.ncib * a.ncob_ * (SP ? 4 : 1);
+    const int nslab = a.ncib * a.ncob_ * (SP ? 2 : 1);
     const int b = blockIdx.x;
     if (a.xcd_remap) {
       const int xcd = b & 7, q = b >> 3;
@@ -159,8 +170,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       ysub = b / nslab;
     }
   }
-  const int par = SP ? (slab & 3) : 0, py = par >> 1, px = par & 1;   // SP: slab = (cob * ncib + cib) * 4 + parity
-  const int slab_ = SP ? (slab >> 2) : slab;
+  const int py = SP ? (slab & 1) : 0;                               // SP: slab = (cob * ncib + cib) * 2 + row parity
+  const int slab_ = SP ? (slab >> 1) : slab;
   const int cib = uni(slab_ % a.ncib), cob = uni(slab_ / a.ncib);
   const int H = SP ? a.Hin : a.Hout, W = SP ? a.Win : a.Wout;   // the grid of X (and of dY')
   const unsigned plane = (unsigned)(H * W);
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         c.r1 = c.r0 + segrows;
         c.R = c.r0 - 1;
         c.xsoff = (unsigned)uni((c.R * W) * 32);
-        c.dsoff = SP ? (unsigned)uni(((2 * (c.r0 - py) + py) * 2 * W + 2 * x0 + px) * 4) : (unsigned)uni((c.r0 * W + x0) * 4);
+        c.dsoff = SP ? (unsigned)uni(((2 * (c.r0 - py) + py) * 2 * W + 2 * x0) * 4) : (unsigned)uni((c.r0 * W + x0) * 4);
         c.xbase = uni_ptr(reinterpret_cast<const char*>(a.x) + ((size_t)n * (a.Cin / 8) + (size_t)cib * 8) * plane * 32);
         c.dbase = uni_ptr(a.dy + (size_t)n * a.Cout * dplane);
         const unsigned ln = threadIdx.x & 63u;
@@ -265,11 +276,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   const int dw16 = dco * P16 + dq * 16, dw8 = DY16 + dco * P8 + dq * 8;
   // conversion of one register set in two pieces placed between MFMA triples: pixels 0-3 | pixels 4-7, each stored at once
   // (8 + 4 + 4 bytes): nothing of a piece lives across an MFMA
-  auto conv_piece = [&](auto pc, auto piece, unsigned char* slot) __attribute__((always_inline)) {
-    constexpr int P = decltype(pc)::value, I = decltype(piece)::value;
+  auto conv_piece = [&](auto pc, auto piecec, unsigned char* slot) __attribute__((always_inline)) {
+    // plain: piece I = pixels 4 I .. 4 I + 3 of the thread's 8; SP: piece 2 pp + I = pixels 4 I .. of column-parity plane pp
+    constexpr int P = decltype(pc)::value, I = decltype(piecec)::value & 1, PP = decltype(piecec)::value >> 1;
     f32x4 d;
-    if constexpr (SP != 0) {   // every other hi-res pixel (the loads start px floats in)
-      d[0] = dr[P][2 * I][0]; d[1] = dr[P][2 * I][2]; d[2] = dr[P][2 * I + 1][0]; d[3] = dr[P][2 * I + 1][2];
+    if constexpr (SP != 0) {   // every other hi-res pixel
+      d[0] = dr[P][2 * I][PP]; d[1] = dr[P][2 * I][PP + 2]; d[2] = dr[P][2 * I + 1][PP]; d[3] = dr[P][2 * I + 1][PP + 2];
+      slot += PP * DYSLOT;
     } else {
       d = dr[P][I];
     }
@@ -315,16 +328,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
 
   // ---- fragment addresses (per-lane constants; slot, tap shift and k-step are immediates)
   // A (dY): lane (r, h) reads row 32 ct + r; f16: 8 pixels at 16 h of the k-step; fp8: the row's 32 bytes of image h
-  const int a16off = (32 * ct + r) * P16 + 16 * h;
-  const int a8off = DY16 + h * DY8 + (32 * ct + r) * P8;
+  const int a16off = pxw * DYSLOT + (32 * ct + r) * P16 + 16 * h;
+  const int a8off = pxw * DYSLOT + DY16 + h * DY8 + (32 * ct + r) * P8;
   // B (X) f16 by ds_read_b64_tr_b16: lane 4q + p of group g supplies pixel q of its 4-pixel block, 8-byte chunk p & 1 of
   // octet 2 (g & 1) + (p >> 1) of the wave's ci-tile; k-half g >> 1
-  const int b16off = (4 * cih + 2 * (g & 1) + ((li & 3) >> 1)) * XP16 + (8 * (g >> 1) + (li >> 2)) * 16 + (li & 1) * 8 + px * 16;
+  const int b16off = (4 * cih + 2 * (g & 1) + ((li & 3) >> 1)) * XP16 + (8 * (g >> 1) + (li >> 2)) * 16 + (li & 1) * 8 + pxw * 16;
   // B fp8 by ds_read_b64_tr_b8: lane 2j + p supplies pixel j of its 8-pixel block, octet 2 (g & 1) + p; K block g >> 1:
   // block 0 = xh' (second 8 bytes of the pixel's 16), block 1 = xl'
-  const int b8off = X16 + cih * X8T + x8off(2 * (g & 1) + (li & 1)) + (li >> 1) * 16 + ((g >> 1) ? 0 : 8) + px * 16;
+  const int b8off = X16 + cih * X8T + x8off(2 * (g & 1) + (li & 1)) + (li >> 1) * 16 + ((g >> 1) ? 0 : 8) + pxw * 16;
 
-  constexpr int NT = SP ? 4 : 9, NKX = SP ? 2 : 3;
+  constexpr int NT = SP ? 8 : 9;   // SP: acc[4 ci-tile + 2 a + b]
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -349,6 +362,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   // ---- prologue: X(0..2) in flight, dY(0) committed, dY(1) in registers, dY(2) noted; the cursor ends at stage 3
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
   step();
   request_x(xs0);
   save_dy();
@@ -359,6 +374,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   request_dy(C1{});
   conv_piece(C0{}, C0{}, dys);
   conv_piece(C0{}, C1{}, dys);
+  if constexpr (SP != 0) {
+    conv_piece(C0{}, C2{}, dys);
+    conv_piece(C0{}, C3{}, dys);
+  }
   step();
   request_x(xs2);
   save_dy();
@@ -393,24 +412,20 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off));
     A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off + 32));
     constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3;   // ring positions of ky = 1, 2 (ky = 0: K)
-    // accumulators: plain acc[3 ky + kx] (ky = 0: ring K, 1: R1, 2: R2); SP acc[2 a + b] (a = 0: ring K, 1: R1)
-    constexpr int T1 = SP ? 2 : 3;
 #pragma unroll
-    for (int kx = 0; kx < NKX; ++kx) {
+    for (int kx = 0; kx < 3; ++kx) {
       const f16x8 b0 = rtr16(xsl + b16off + kx * 16, xsl + b16off + (kx + 4) * 16);
       if (kx == KCNV) {
-        // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3) -- two operations each (SP: four for a dY row)
-        if constexpr (SP != 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3) -- two operations each
         if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma8(acc[T1 + kx], A8[R1], b8, sc_a, sc_b);
+      mfma8(acc[3 + kx], A8[R1], b8, sc_a, sc_b);
       if (kx == KREQ) {
         __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
         if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
       }
-      if constexpr (SP == 0) mfma8(acc[6 + kx], A8[R2], b8, sc_a, sc_b);
+      mfma8(acc[6 + kx], A8[R2], b8, sc_a, sc_b);
       if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) {
         request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
         save_dy();
@@ -421,23 +436,94 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       const f16x8 b1 = rtr16(xsl + b16off + (kx + 16) * 16, xsl + b16off + (kx + 20) * 16);
       if (kx == KCNV && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
       __builtin_amdgcn_sched_barrier(0);
-      mfma16(acc[T1 + kx], A16[R1][0], b0);
-      if constexpr (SP == 0) mfma16(acc[6 + kx], A16[R2][0], b0);
+      mfma16(acc[3 + kx], A16[R1][0], b0);
+      mfma16(acc[6 + kx], A16[R2][0], b0);
       mfma16(acc[kx], A16[K][0], b0);
       __builtin_amdgcn_sched_barrier(0);
-      if (kx < NKX - 1) b8 = rtr8(xsl + b8off + (kx + 1) * 16);
+      if (kx < 2) b8 = rtr8(xsl + b8off + (kx + 1) * 16);
       else b8 = rtr8(xslot_of(std::integral_constant<int, (Q + 1) % 4>{}) + b8off);   // the next stage's first B fragment
       __builtin_amdgcn_sched_barrier(0);
-      mfma16(acc[T1 + kx], A16[R1][1], b1);
-      if constexpr (SP == 0) mfma16(acc[6 + kx], A16[R2][1], b1);
+      mfma16(acc[3 + kx], A16[R1][1], b1);
+      mfma16(acc[6 + kx], A16[R2][1], b1);
       mfma16(acc[kx], A16[K][1], b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // X(s + 2) has landed when at most this stage's operations (dY(s + 2), X(s + 3)) are outstanding
-    if constexpr (SP != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // X(s + 2) has landed when at most this stage's four operations are outstanding
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     // a RAW barrier behind the counted wait above: __syncthreads() carries a release fence = s_waitcnt vmcnt(0), which made
     // every stage wait for the dY row and X row it had just requested for the stages after it
+    if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  // SP stage: ring of TWO rows (K = new row s + 1 - py, R1 = the row before it), two dY slots, four sub-steps (kx, ci-tile) of
+  // 2 + 4 MFMAs; the requests ride in sub-step 0, the four conversion pieces of dY row s + 1 in sub-steps 1 and 2.
+  auto body_sp = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value, K = S % 2, R1 = K ^ 1, P = S % 2, Q = S % 4;
+    using PC = std::integral_constant<int, P>;
+    using PN = std::integral_constant<int, P ^ 1>;
+    const unsigned char* dsl = dys + K * (2 * DYSLOT);
+    unsigned char* dnx = dys + R1 * (2 * DYSLOT);
+    const unsigned char* xsl = xslot_of(std::integral_constant<int, Q>{});
+    {
+      const i32x4 l = *reinterpret_cast<const i32x4*>(dsl + a8off), u = *reinterpret_cast<const i32x4*>(dsl + a8off + 16);
+      A8[K] = (i32x8)__builtin_shufflevector(l, u, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off));
+    A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off + 32));
+    static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+      constexpr int IT = decltype(itc)::value, kx = IT >> 1, ci = IT & 1;
+      constexpr int XO16 = ci * 4 * XP16, XO8 = ci * X8T;
+      f32x16& accK = acc[4 * ci + kx];        // a = 0: the new row
+      f32x16& accR = acc[4 * ci + 2 + kx];    // a = 1: the row before it
+      const f16x8 b0 = rtr16(xsl + b16off + XO16 + kx * 16, xsl + b16off + XO16 + (kx + 4) * 16);
+      if constexpr (IT == 1) {
+        // newer than dY(s + 1): X(s + 2) (2 operations), dY(s + 2) (4), X(s + 3) (2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
+      }
+      if constexpr (IT == 2) {
+        if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C2{}, dnx);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(accR, A8[R1], b8, sc_a, sc_b);
+      if constexpr (IT == 0) {
+        __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
+        if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
+      }
+      mfma8(accK, A8[K], b8, sc_a, sc_b);
+      if constexpr (IT == 0) {
+        if (!(EOVAE_ROWS_ABL & 2)) {
+          request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
+          save_dy();
+          step();
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 b1 = rtr16(xsl + b16off + XO16 + (kx + 16) * 16, xsl + b16off + XO16 + (kx + 20) * 16);
+      if constexpr (IT == 1) {
+        if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
+      }
+      if constexpr (IT == 2) {
+        if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C3{}, dnx);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(accR, A16[R1][0], b0);
+      mfma16(accK, A16[K][0], b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT < 3) {
+        constexpr int nkx = (IT + 1) >> 1, nci = (IT + 1) & 1;
+        b8 = rtr8(xsl + b8off + nci * X8T + nkx * 16);
+      } else {
+        b8 = rtr8(xslot_of(std::integral_constant<int, (Q + 1) % 4>{}) + b8off);   // the next stage's first B fragment
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(accR, A16[R1][1], b1);
+      mfma16(accK, A16[K][1], b1);
+      __builtin_amdgcn_sched_barrier(0);
+      (void)XO8;
+    });
+    // X(s + 2) has landed when at most this stage's operations (dY(s + 2): 4, X(s + 3): 2) are outstanding
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
@@ -447,18 +533,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   auto run = [&](auto rolec) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int s = 0; s < nst; s += 12) {
-      body(std::integral_constant<int, 0>{}, rolec);
-      body(std::integral_constant<int, 1>{}, rolec);
-      body(std::integral_constant<int, 2>{}, rolec);
-      body(std::integral_constant<int, 3>{}, rolec);
-      body(std::integral_constant<int, 4>{}, rolec);
-      body(std::integral_constant<int, 5>{}, rolec);
-      body(std::integral_constant<int, 6>{}, rolec);
-      body(std::integral_constant<int, 7>{}, rolec);
-      body(std::integral_constant<int, 8>{}, rolec);
-      body(std::integral_constant<int, 9>{}, rolec);
-      body(std::integral_constant<int, 10>{}, rolec);
-      body(std::integral_constant<int, 11>{}, rolec);
+      if constexpr (SP != 0) {
+        static_for<0, 12>([&](auto sc) __attribute__((always_inline)) { body_sp(sc); });
+      } else {
+        static_for<0, 12>([&](auto sc) __attribute__((always_inline)) { body(sc, rolec); });
+      }
     }
   };
   if (EOVAE_ROWS_ROLES && wave >= 4) run(C1{}); else run(C0{});
@@ -472,13 +551,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     if (dq == 0) atomicAdd(&a.db[cob * 128 + dco], v);
   }
   // this block's partial tile [tap][128 co][64 ci], folded in a fixed order by wgrad_fold_kernel
-  float* pt = a.part + (((size_t)slab * a.split + ysub) * NT) * (128 * 64) + cih * 32 + r;
+  // (SP: eight tiles per block [px][2 a + b][128 co][64 ci]; the wave holds [ci-tile][2 a + b] of its px)
+  float* pt = a.part + (((size_t)slab * a.split + ysub) * (SP ? 8 : 9) + (SP ? 4 * pxw : 0)) * (128 * 64) + cih * 32 + r;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int col = ct * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      pt[(size_t)t * (128 * 64) + col * 64] = acc[t][q] * dyinv;
+      if constexpr (SP != 0) pt[(size_t)(t & 3) * (128 * 64) + col * 64 + (t >> 2) * 32] = acc[t][q] * dyinv;
+      else pt[(size_t)t * (128 * 64) + col * 64] = acc[t][q] * dyinv;
     }
 }
 
@@ -525,7 +606,7 @@ __global__ __launch_bounds__(256) void f16c8_records_kernel(const float* __restr
   r[1] = a1;
 }
 
-// dW[co][ci][KY][KX] of the upsample layer from the parity tiles: part[(slab * 4 + p) * split + y][2 a + b][128][64];
+// dW[co][ci][KY][KX] of the upsample layer from the parity tiles: part[(slab * 2 + py) * split + y][4 px + 2 a + b][128][64];
 // tap (KY, KX) of the layer's kernel lands on (a, b) = (KY + py - 1 >= 1 ? .. ) of parity (py, px):
 //   py = 0: KY = 0 -> a = 0, KY = 1, 2 -> a = 1;   py = 1: KY = 0, 1 -> a = 0, KY = 2 -> a = 1   (same for KX, px, b).
 // Splits and parities are summed in a fixed order (deterministic).
@@ -544,14 +625,14 @@ __global__ __launch_bounds__(256) void wgrad_up_fold_kernel(const float* __restr
     const int py = p >> 1, px = p & 1;
     const int a_ = py == 0 ? (KY == 0 ? 0 : 1) : (KY == 2 ? 1 : 0);
     const int b_ = px == 0 ? (KX == 0 ? 0 : 1) : (KX == 2 ? 1 : 0);
-    const float* q = part + ((((size_t)slab * 4 + p) * split) * 4 + (2 * a_ + b_)) * (128 * 64) + (co & 127) * 64 + (ci & 63);
+    const float* q = part + ((((size_t)slab * 2 + py) * split) * 8 + 4 * px + (2 * a_ + b_)) * (128 * 64) + (co & 127) * 64 + (ci & 63);
     float s0 = 0.f, s1 = 0.f;
     int y = 0;
     for (; y + 1 < split; y += 2) {
-      s0 += q[(size_t)y * 4 * 128 * 64];
-      s1 += q[(size_t)(y + 1) * 4 * 128 * 64];
+      s0 += q[(size_t)y * 8 * 128 * 64];
+      s1 += q[(size_t)(y + 1) * 8 * 128 * 64];
     }
-    if (y < split) s0 += q[(size_t)y * 4 * 128 * 64];
+    if (y < split) s0 += q[(size_t)y * 8 * 128 * 64];
     s += s0 + s1;
   }
   dw[((size_t)co * Cin + ci) * 9 + tap] = s;
@@ -582,7 +663,7 @@ void eovae_c8_wgrad_rows_launch(WgCArgs& a, hipStream_t st) {
 #define EOVAE_WGRAD_BLOCKS 256   // one block per CU (conv_f16c8.hip)
 #endif
 static int up_rows_split(int Cin, int Cout) {
-  int split = EOVAE_WGRAD_BLOCKS / (4 * cdiv(Cin, 64) * cdiv(Cout, 128));
+  int split = EOVAE_WGRAD_BLOCKS / (2 * cdiv(Cin, 64) * cdiv(Cout, 128));
   return split < 1 ? 1 : split;
 }
 
@@ -593,11 +674,11 @@ int eovae_conv3x3_f16c8_wgrad_up_eligible(int N, int Cin, int H, int W, int Cout
          (long long)H * W * 32 * 8 < (1LL << 31) && (long long)Cout * H * W * 16 < (1LL << 32);
 }
 
-// scratch: the records of x (4 B per element) + one [4][128][64] fp32 tile per block
+// scratch: the records of x (4 B per element) + eight [128][64] fp32 tiles per block
 size_t eovae_conv3x3_f16c8_wgrad_up_workspace(int N, int Cin, int H, int W, int Cout) {
   if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   const size_t rec = ((size_t)N * Cin * H * W * 4 + 255) / 256 * 256;
-  return rec + (size_t)4 * cdiv(Cin, 64) * cdiv(Cout, 128) * up_rows_split(Cin, Cout) * 4 * 128 * 64 * sizeof(float);
+  return rec + (size_t)2 * cdiv(Cin, 64) * cdiv(Cout, 128) * up_rows_split(Cin, Cout) * 8 * 128 * 64 * sizeof(float);
 }
 
 // Weight gradient of conv3x3(nearest_upsample_x2(x)): x fp32 [N][Cin][H][W], dy fp32 [N][Cout][2H][2W] -> dw[Cout][Cin][3][3]
@@ -626,7 +707,7 @@ int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, flo
   a.nseg = nseg;
   a.units = strips * nseg;
   if (a.split > a.units) a.split = a.units;
-  const int nslab = 4 * a.ncib * a.ncob_;
+  const int nslab = 2 * a.ncib * a.ncob_;
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<1>, dim3(nslab * a.split), dim3(512), 0, st, a);
   const size_t total = (size_t)9 * Cout * Cin;
