@@ -461,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 
   // Epilogue of one tile: as conv_bf16x3.hip (batched unconditional bias / residual loads, plain stores on
   // full tiles), plus the exact power-of-two un-scaling of a scaled input.
+  float omax = 0.f;   // max |y| over everything this lane stores (a.out_amax)
   auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
     const int ox = t.ox0 + r;
     const bool okx = ox < a.Wout;
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
             for (int j = 0; j < NI; ++j) {
               v[k][j] = acc[i][j][4 * qq + k] * xinv + bias4[k] + rv[qq][k][j];
               if (!FULL) asm volatile("" : "+v"(v[k][j]));
+              omax = __builtin_fmaxf(omax, (FULL || (cok[k] && rowok[j])) ? __builtin_fabsf(v[k][j]) : 0.f);
             }
           if (a.gn_sums) {
             // statistics of the following GroupNorm from the values being stored: the 4 channels of this batch
@@ -771,6 +773,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   if (gn_pend) {
     stage_barrier(IC0{});
     gn_flush(gn_n, gn_cb);
+  }
+  if (a.out_amax) {   // uniform
+    const float mx = wave_max(omax);
+    if (lane == 0 && mx > 0.f && mx < 3.0e38f) atomicMax(a.out_amax, __builtin_bit_cast(unsigned, mx));   // NaN / inf never land
   }
 }
 
@@ -1770,10 +1776,25 @@ int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Ho
 // 3x3 stride-1 conv / data gradient with f16c8 operands.  Arguments as eovae_conv3x3_bf16_fwd; the GEMM K
 // channel count must be a multiple of 32.  xamax: device pointer to the float bits of max |x|
 // (eovae_absmax_bits) when x may sit outside f16's range (gradients), else NULL.
+int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bias, const float* residual, float* y,
+                                 const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
+                                 int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
+                                 unsigned* out_amax, void* stream);
+
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual, float* y,
                             const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
                             int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                             void* stream) {
+  return eovae_conv3x3_f16c8_fwd_amax(x, wp, bias, residual, y, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, mode, subpix, xpacked,
+                                      gn_sums, gn_groups, nullptr, stream);
+}
+
+// As eovae_conv3x3_f16c8_fwd; out_amax (nullable, a pre-zeroed device word) receives the float bits of max|y| by atomicMax
+// from the epilogue: the range pre-scale of the layer that reads y, without a reduction pass over y.
+int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bias, const float* residual, float* y,
+                                 const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
+                                 int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
+                                 unsigned* out_amax, void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_f16c8_fwd: null pointer");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_f16c8_fwd: bad shape");
   EOVAE_CHECK_ARG(mode == MODE_NORMAL, "conv3x3_f16c8_fwd: mode %d unsupported (stride-1 'normal' layers and the "
@@ -1782,7 +1803,7 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   ConvCArgs a;
   a.x = x; a.wp = (const unsigned char*)wp; a.bias = bias; a.res = residual; a.y = y; a.xamax = xamax;
   a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1; a.packed = xpacked;
-  a.stagger = 0; a.skew = 0;
+  a.stagger = 0; a.skew = 0; a.out_amax = out_amax;
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && !xamax), "conv3x3_f16c8_fwd: packed input is a forward, plain 3x3 input");
   if (subpix == 0) {
     const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;
@@ -1836,6 +1857,13 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
   // every CU at least two of its tiles
   if (eovae_c8_w4_eligible(a, subpix, n_cu)) {
     eovae_c8_w4_launch(a, n_cu, st);
+    if (out_amax) {   // that kernel's epilogue has no register for a running maximum (+70 spills): one pass over y instead
+      const size_t n = (size_t)N * Cout * Hout * Wout;
+      size_t blocks = (n / 4 + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, n, out_amax);
+    }
     EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_fwd (w4)");
     return EOVAE_OK;
   }

@@ -22,6 +22,8 @@ struct ConvCArgs {
   int gn_groups, gn_shift;   // channel groups of the GroupNorm that reads y; log2(channels per group)
   int stagger;               // conv_f16c8_w4.hip: start delay per block group, in units of 1024 shader cycles
   int skew;                  // conv_f16c8_w4.hip, two blocks per CU: start delay of a CU's second block, units of 4096 cycles
+  unsigned* out_amax;        // float bits of max|y| (atomicMax into a pre-zeroed word), or null: the range pre-scale of the
+                             // layer that reads y (stride-2 / x2-upsample / data-gradient inputs) without a pass over y
 };
 
 // weight-gradient argument block (conv_f16c8.hip wgrad3x3_f16c8_kernel, conv_f16c8_wgrad_w4.hip)

@@ -36,6 +36,7 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_pack_pair': (_i, [_p, _p, _p, _i, _i, _f, _p]),
     'eovae_conv3x3_f16c8_pack_multi': (_i, [_p, _i, _f, _p]),
     'eovae_conv3x3_f16c8_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    'eovae_conv3x3_f16c8_fwd_amax': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     'eovae_conv3x3_f16c8_which': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv3x3_f16c8_wgrad_dw_workspace': (_sz, [_i, _i]),

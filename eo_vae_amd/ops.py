@@ -303,15 +303,16 @@ def _pack3x3(w4, rows, cols, flip, f16c8):
 
 
 def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None,
-               packed=False, gn_sums=None):
+               packed=False, gn_sums=None, out_amax=None):
+    """out_amax (f16c8 only): a zeroed [1] int32 that receives the float bits of max|y| from the kernel's epilogue."""
     lib = L.load()
     if packed and not f16c8:
         raise L.EovaeError('conv2d: operand-record input reached a non-f16c8 kernel')
     if f16c8:
-        L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
-                                            L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
-                                            int(packed), L.ptr(gn_sums), GN_GROUPS_HINT if gn_sums is not None else 0,
-                                            L.stream()), 'eovae_conv3x3_f16c8_fwd')
+        L.check(lib.eovae_conv3x3_f16c8_fwd_amax(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
+                                                 L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
+                                                 int(packed), L.ptr(gn_sums), GN_GROUPS_HINT if gn_sums is not None else 0,
+                                                 L.ptr(out_amax), L.stream()), 'eovae_conv3x3_f16c8_fwd')
     else:
         L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
                                            cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], subpix,
@@ -475,11 +476,14 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
         ev0.record()
     if packed and not f8:
         raise L.EovaeError('conv2d: operand-record input needs the f16c8 kernel (K % 32 == 0, mode normal)')
-    global _LAST_GN_SUMS
+    global _LAST_GN_SUMS, _LAST_OUT_AMAX
     sums = _gn_sums_buffer(n, cout_gemm, x.device) if f8 and not flip else None
+    oa = None   # (forward outputs are not tagged: most come from the one-wave-per-SIMD kernel, whose epilogue has no
+                # register for a running maximum, and are read un-normalised by 6 of ~60 layers only)
     _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, None if packed else amax,
-               packed, sums)
+               packed, sums, oa)
     _LAST_GN_SUMS = sums
+    _LAST_OUT_AMAX = oa
     if timed:
         ev1.record()
     return y
@@ -491,6 +495,8 @@ SUBPIX_UPSAMPLE = os.environ.get('EOVAE_SUBPIX', '1') != '0'
 
 
 UP_WGRAD_ROWS = True   # False: the tile kernel's sub-pixel mode (tests, A/B)
+EPILOGUE_AMAX = os.environ.get('EOVAE_EPILOGUE_AMAX', '1') != '0'   # max|y| from the convolution epilogues (0: reduction passes)
+_LAST_OUT_AMAX = None
 
 
 def _subpix_ok(weight):
@@ -542,8 +548,11 @@ def down_conv_s2d_dgrad(dy, weight, h, w):
     f8 = _use_f16c8(cout)
     wp = _down_packed(weight, True, f8)
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
+    oa = zeros_small(1, torch.int32, dy.device) if (f8 and EPILOGUE_AMAX) else None
     _launch3x3(dy, wp, None, None, dx, n, cout, h // 2, w // 2, cin, h, w, MODE_NORMAL, 4, f8,
-               amax_of(dy) if f8 else None)
+               amax_of(dy) if f8 else None, out_amax=oa)
+    if oa is not None:
+        _tag_amax(dx, oa)      # read by the data gradient of the block in front of this layer
     return dx
 
 
@@ -590,8 +599,11 @@ def up_conv_subpix_dgrad(dy, weight, h, w):
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
                                          4.0 * (dy.numel() + dx.numel() + weight.numel()))
         ev0.record()
+    oa = zeros_small(1, torch.int32, dy.device) if (f8 and EPILOGUE_AMAX) else None
     _launch3x3(dy, wp, None, None, dx, n, cout, 2 * h, 2 * w, cin, h, w, MODE_NORMAL, 2, f8,
-               amax_of(dy) if f8 else None)
+               amax_of(dy) if f8 else None, out_amax=oa)
+    if oa is not None:
+        _tag_amax(dx, oa)
     if timed:
         ev1.record()
     return dx
@@ -814,12 +826,16 @@ class Conv2dFn(torch.autograd.Function):
 
 
 def conv2d(x, weight, bias=None, residual=None, mode='normal'):
-    global _LAST_GN_SUMS
+    global _LAST_GN_SUMS, _LAST_OUT_AMAX
     _LAST_GN_SUMS = None
+    _LAST_OUT_AMAX = None
     y = Conv2dFn.apply(x, weight, bias, residual, mode)
     if _LAST_GN_SUMS is not None:
         y._eovae_gn_sums = (_LAST_GN_SUMS, GN_GROUPS_HINT, y._version)
         _LAST_GN_SUMS = None
+    if _LAST_OUT_AMAX is not None:
+        _tag_amax(y, _LAST_OUT_AMAX)
+        _LAST_OUT_AMAX = None
     return y
 
 

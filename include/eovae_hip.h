@@ -104,6 +104,12 @@ int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, c
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                             void* stream);
+/* as above; out_amax (nullable, pre-zeroed device word) receives the float bits of max|y| from the epilogue (atomicMax):
+ * the range pre-scale of the layer that reads y without a reduction pass over y */
+int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bias, const float* residual,
+                            float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
+                            int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups, unsigned* out_amax,
+                            void* stream);
 /* which kernel the call above launches for these arguments: 1 = conv3x3_f16c8_w4_kernel (csrc/conv_f16c8_w4.hip: one wave
  * per SIMD, 4 x 4 register blocking, 16-row tiles -- plain layers that give every CU two tiles), 0 =
  * conv3x3_f16c8_kernel (8 waves, 8-row tiles: sub-pixel / space-to-depth forms, small grids).  No launch. */

@@ -625,3 +625,37 @@ def test_fused_groupnorm_sums_with_offset_activations(ratio, bar, prec):
         fused = ops.group_norm_silu(y, gam, bet)
         ref = F.silu(F.group_norm(y.double().cpu(), 32, gam.double().cpu(), bet.double().cpu(), eps=1e-6))
     assert rel(fused, ref) < bar
+
+
+def test_epilogue_amax_equals_a_reduction_pass():
+    """max|y| reported by the convolution epilogues (eovae_conv3x3_f16c8_fwd_amax) = eovae_absmax_bits(y), bit for bit:
+    the 8-wave kernel's plain / x2-upsample data-gradient / stride-2 data-gradient forms, and the entry's pass behind the
+    one-wave-per-SIMD kernel; the data gradients tag their result for the layer in front of them."""
+    from eo_vae_amd import ops
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    try:
+        torch.manual_seed(9)
+        # (a) data gradients of the x2-upsample and the stride-2 layers: tagged results
+        w = torch.randn(128, 128, 3, 3, device='cuda') / 34
+        dy = torch.randn(2, 128, 32, 64, device='cuda') * 1e-3
+        dx = ops.up_conv_subpix_dgrad(dy, w, 16, 32)
+        tag = dx._eovae_amax
+        assert tag[1] == dx._version and torch.equal(tag[0], ops.absmax_bits(dx))
+        assert ops.amax_of(dx) is tag[0]
+        dy2 = torch.randn(2, 128, 16, 32, device='cuda') * 1e-3
+        dx2 = ops.down_conv_s2d_dgrad(dy2, w, 32, 64)
+        assert torch.equal(dx2._eovae_amax[0], ops.absmax_bits(dx2))
+        # (b) the plain entry with a residual, on both kernels (N = 16 at 128 x 128 goes to the one-wave-per-SIMD kernel)
+        for n, hw in ((2, 32), (16, 128)):
+            x = torch.randn(n, 128, hw, hw, device='cuda')
+            res = torch.randn(n, 128, hw, hw, device='cuda') * 3
+            b = torch.randn(128, device='cuda')
+            wp = ops._pack3x3(w, 128, 128, False, True)
+            y = torch.empty_like(x)
+            oa = torch.zeros(1, dtype=torch.int32, device='cuda')
+            ops._launch3x3(x, wp, b, res, y, n, 128, hw, hw, 128, hw, hw, ops.MODE_NORMAL, 0, True, ops.range_amax(x),
+                           out_amax=oa)
+            assert torch.equal(oa, ops.absmax_bits(y)), (n, hw)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_PRECISION = old
