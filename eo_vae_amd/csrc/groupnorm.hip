@@ -112,11 +112,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // then copy records into LDS with no conversion work -- the conversion is done ONCE here, in a kernel that is
 // HBM-bound anyway, instead of once per 128-co block of the forward and once per block of the weight gradient.
 // One thread = one pixel x 8 channels; grid = N * C/8 * ceil(HW / 256).
-template <bool SILU>
+// FROM_SUMS: the statistics arrive as the producing convolution's (sum, sum of squares) per (image, group) in double
+// (conv epilogue, gn_sums) and are finished HERE -- the arithmetic of gn_finalize_kernel, once per block for the <= 8
+// groups its channel octet touches -- instead of by a 5 us launch in front of every GroupNorm (52 per step); the
+// block of pixel chunk 0 also leaves (mean, rstd) in `stats` for the backward pass.
+template <bool SILU, bool FROM_SUMS>
 __global__ __launch_bounds__(256) void gn_apply_packed_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
-                                                              const float* __restrict__ stats,
+                                                              float* __restrict__ stats,
+                                                              const double* __restrict__ sums, double inv_count, float eps,
                                                               int* __restrict__ pa, int C, int HW, int cpg,
                                                               int pblocks) {
   typedef int i32x4v __attribute__((ext_vector_type(4)));
@@ -124,13 +129,32 @@ __global__ __launch_bounds__(256) void gn_apply_packed_kernel(const float* __res
   const int pb = blockIdx.x % pblocks, og = blockIdx.x / pblocks;   // og = n * C/8 + octet
   const int oct = og % (C / 8), n = og / (C / 8);
   const int p = pb * 256 + threadIdx.x;
+  __shared__ float st_s[8][2];
+  if constexpr (FROM_SUMS) {
+    if (threadIdx.x < 8) {
+      const int c = oct * 8 + threadIdx.x;
+      const int ng = n * (C / cpg) + c / cpg;
+      const double s_ = sums[(size_t)ng * 2], q_ = sums[(size_t)ng * 2 + 1];
+      const double mean = s_ * inv_count;
+      double var = q_ * inv_count - mean * mean;
+      if (var < 0) var = 0;
+      const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+      st_s[threadIdx.x][0] = m;
+      st_s[threadIdx.x][1] = r;
+      if (pb == 0 && c % cpg == 0) {
+        stats[2 * ng] = m;
+        stats[2 * ng + 1] = r;
+      }
+    }
+    __syncthreads();
+  }
   if (p >= HW) return;
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = oct * 8 + j;
     const int ng = n * (C / cpg) + c / cpg;
-    const float mean = stats[2 * ng], rstd = stats[2 * ng + 1];
+    const float mean = FROM_SUMS ? st_s[j][0] : stats[2 * ng], rstd = FROM_SUMS ? st_s[j][1] : stats[2 * ng + 1];
     const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
     float o = x[((size_t)n * C + c) * HW + p] * sc + sh;
     v[j] = SILU ? silu_f(o) : o;
@@ -902,16 +926,27 @@ int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* be
   const size_t gsize = (size_t)cpg * HW;
   const int ns = nsplit_for(gsize);
   double* part = (double*)ws;
-  if (!sums) hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, sums ? sums : part, stats,
-                     N * G, sums ? 1 : ns, 1.0 / (double)gsize, eps);
   const int pblocks = cdiv(HW, 256);
+  const dim3 grid(N * (C / 8) * pblocks);
+  const double inv_count = 1.0 / (double)gsize;
+  if (sums) {   // statistics from the producing convolution's epilogue: finished inside the apply kernel
+    if (silu)
+      hipLaunchKernelGGL((gn_apply_packed_kernel<true, true>), grid, dim3(256), 0, st, x, gamma, beta, stats, sums, inv_count, eps,
+                         (int*)pa, C, HW, cpg, pblocks);
+    else
+      hipLaunchKernelGGL((gn_apply_packed_kernel<false, true>), grid, dim3(256), 0, st, x, gamma, beta, stats, sums, inv_count,
+                         eps, (int*)pa, C, HW, cpg, pblocks);
+    EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed");
+    return EOVAE_OK;
+  }
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats, N * G, ns, inv_count, eps);
   if (silu)
-    hipLaunchKernelGGL(gn_apply_packed_kernel<true>, dim3(N * (C / 8) * pblocks), dim3(256), 0, st, x, gamma, beta,
-                       stats, (int*)pa, C, HW, cpg, pblocks);
+    hipLaunchKernelGGL((gn_apply_packed_kernel<true, false>), grid, dim3(256), 0, st, x, gamma, beta, stats, (const double*)nullptr,
+                       inv_count, eps, (int*)pa, C, HW, cpg, pblocks);
   else
-    hipLaunchKernelGGL(gn_apply_packed_kernel<false>, dim3(N * (C / 8) * pblocks), dim3(256), 0, st, x, gamma,
-                       beta, stats, (int*)pa, C, HW, cpg, pblocks);
+    hipLaunchKernelGGL((gn_apply_packed_kernel<false, false>), grid, dim3(256), 0, st, x, gamma, beta, stats,
+                       (const double*)nullptr, inv_count, eps, (int*)pa, C, HW, cpg, pblocks);
   EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed");
   return EOVAE_OK;
 }
