@@ -1,9 +1,10 @@
 """Wavelength-conditioned first/last convolutions (reference: modules/dynamic_conv.py).
 
 The tiny hyper-network (sin-cos embedding -> FCResLayer -> 4-layer post-norm transformer over
-[128 weight tokens | C wave tokens | 1 bias token]) stays on PyTorch-ROCm ops (< 0.3 GFLOP,
-SURVEY.md 2b K14); the convolution with the generated kernel and its three gradients run on
-the HIP implicit-GEMM kernels."""
+[128 weight tokens | C wave tokens | 1 bias token], < 0.3 GFLOP): its encoder layers and Linear
+layers run on the small exact-fp32 kernels of csrc/generator.hip (generator_ops.py; round 4), the element-wise glue
+around them on PyTorch-ROCm ops; the convolution with the generated kernel and its three gradients run on the HIP
+implicit-GEMM / thin-layer kernels."""
 from __future__ import annotations
 
 import os
@@ -66,6 +67,9 @@ def prefer_rocblas_for_generator():
     """Switch PyTorch's GEMM backend to rocBLAS (process-wide; every other GEMM of this product is its own HIP kernel).
     Returns the name of the backend in force afterwards; logs it once."""
     if _BLAS_STATE['backend'] is not None:
+        return _BLAS_STATE['backend']
+    if GENERATOR_KERNELS:    # round 4: the generators run on this product's own kernels -- no process-wide switch to make
+        _BLAS_STATE['backend'] = 'none (own HIP kernels, csrc/generator.hip)'
         return _BLAS_STATE['backend']
     backend = 'default'
     if os.environ.get('EOVAE_GENERATOR_BLAS', 'rocblas') == 'rocblas':

@@ -117,10 +117,11 @@ def test_dynamic_convs_against_golden(golden):
 
 
 def test_dynamic_convs_with_the_default_blas_library():
-    """a host application that embeds the model without calling prefer_rocblas_for_generator() (or with
-    EOVAE_GENERATOR_BLAS=keep) runs the hyper-networks on PyTorch's default GEMM library (hipBLASLt).  Covered here in a
-    fresh process (the BLAS preference is process-wide and this session has already chosen rocBLAS): generated kernels
-    against the reference fixture at a bar that holds for either library (observed up to 1.8e-4 with hipBLASLt)."""
+    """the PyTorch-op formulation of the hyper-networks (EOVAE_GENERATOR_KERNELS=0 since round 4) in a host
+    application that does not call prefer_rocblas_for_generator() (or sets EOVAE_GENERATOR_BLAS=keep) runs on PyTorch's
+    default GEMM library (hipBLASLt).  Covered in a fresh process (the BLAS preference is process-wide): generated kernels
+    against the reference fixture at a bar that holds for either library (observed up to 1.8e-4 with hipBLASLt).  With the
+    default own kernels the function changes nothing and says so."""
     import subprocess
     import sys
     code = r"""
@@ -144,7 +145,10 @@ for mod, wl in O.WAVELENGTHS.items():
 print('WORST', worst)
 assert worst < 5e-4, worst
 """
-    env = dict(os.environ, EOVAE_GENERATOR_BLAS='keep')
+    from eo_vae_amd import dynamic_conv
+    if dynamic_conv.GENERATOR_KERNELS and dynamic_conv.generator_blas_backend() is None:
+        assert dynamic_conv.prefer_rocblas_for_generator().startswith('none')
+    env = dict(os.environ, EOVAE_GENERATOR_BLAS='keep', EOVAE_GENERATOR_KERNELS='0')
     env.pop('DISABLE_ADDMM_CUDA_LT', None)
     r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
                        capture_output=True, text=True, timeout=600)
