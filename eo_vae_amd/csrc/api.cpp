@@ -27,6 +27,7 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
     {"c8_w4_stagger", "EOVAE_C8_W4_STAGGER", 0},
     {"c8_w4_skew", "EOVAE_C8_W4_SKEW", -1},
     {"c8_wgrad_w4", "EOVAE_C8_WGRAD_W4", 0},       // conv_f16c8_wgrad_w4.hip (parked: slower than the 8-wave kernels)
+    {"c8_pack_gather", "EOVAE_C8_PACK_GATHER", 0}, // per-layer weight packs by the per-element gather kernel (reference of the LDS-staged one)
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};

@@ -1579,40 +1579,42 @@ __global__ __launch_bounds__(256) void pack_multi_amax_kernel(const PackDesc* __
 // stages a 32 co x 32 ci x 9 tap sub-block in LDS (32 contiguous 1,152-byte rows) and writes the 9 x 2 tile pieces it
 // owns: 512-byte runs in the packed images.  Same arithmetic per element as pack_f16c8_body (bit-identical output).
 constexpr int PKB = 32, PKP = PKB * 9 + 1;
-__global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ descs, float scale) {
+// wp_fwd / wp_bwd: either may be null (that orientation is skipped); parts: the amax partials of the UNSCALED weights
+__device__ __forceinline__ void pack_tiles_body(const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
+                                                unsigned char* __restrict__ wp_bwd, int Cout, int Cin, float scale,
+                                                const float* __restrict__ parts, int nparts, unsigned bid, unsigned nblk) {
   __shared__ float tile[PKB * PKP];
   __shared__ float wmax_s[4];
-  const PackDesc d = descs[blockIdx.y];
   const int tid = threadIdx.x;
   {
-    float m = tid < PACK_MULTI_PARTS ? pack_parts_of(d)[tid] : 0.f;
+    float m = tid < nparts ? parts[tid] : 0.f;
     m = wave_max(m);
     if ((tid & 63) == 0) wmax_s[tid >> 6] = m;
     __syncthreads();
   }
   const float wmax = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
   // orientation 0 (forward): k = ci, m = co;  1 (data gradient): k = co, m = ci, taps reversed
-  const int nchunk0 = cdiv_d(d.Cin, 32), ncob0 = cdiv_d(d.Cout, 128);
-  const int nchunk1 = cdiv_d(d.Cout, 32), ncob1 = cdiv_d(d.Cin, 128);
-  if (blockIdx.x == 0 && tid == 0) {
+  const int nchunk0 = cdiv_d(Cin, 32), ncob0 = cdiv_d(Cout, 128);
+  const int nchunk1 = cdiv_d(Cout, 32), ncob1 = cdiv_d(Cin, 128);
+  if (bid == 0 && tid == 0) {
     const unsigned wbits = __builtin_bit_cast(unsigned, wmax);
-    *reinterpret_cast<unsigned*>(d.wp_fwd + (size_t)9 * nchunk0 * ncob0 * 16384) = wbits;
-    *reinterpret_cast<unsigned*>(d.wp_bwd + (size_t)9 * nchunk1 * ncob1 * 16384) = wbits;
+    if (wp_fwd) *reinterpret_cast<unsigned*>(wp_fwd + (size_t)9 * nchunk0 * ncob0 * 16384) = wbits;
+    if (wp_bwd) *reinterpret_cast<unsigned*>(wp_bwd + (size_t)9 * nchunk1 * ncob1 * 16384) = wbits;
   }
   const float amax = wmax * fabsf(scale);
   const int e1 = amax > 0.f ? 7 - expo_of_bits(__builtin_bit_cast(unsigned, amax)) : 0;
   const float s_hi = pow2f(e1), s_lo = pow2f(e1 + 12);
   const int cobk = ncob0 * 4, cibk = ncob1 * 4;          // 32-blocks over the 128-padded extents
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  for (int blk = blockIdx.x; blk < cobk * cibk; blk += gridDim.x) {
+  for (int blk = (int)bid; blk < cobk * cibk; blk += (int)nblk) {
     const int co0 = (blk / cibk) * PKB, ci0 = (blk % cibk) * PKB;
-    const bool fwd = ci0 < nchunk0 * 32, bwd = co0 < nchunk1 * 32;
+    const bool fwd = wp_fwd && ci0 < nchunk0 * 32, bwd = wp_bwd && co0 < nchunk1 * 32;
     if (!fwd && !bwd) continue;
-    const int ncol = max(0, min(PKB, d.Cin - ci0)) * 9;
+    const int ncol = max(0, min(PKB, Cin - ci0)) * 9;
     __syncthreads();                                     // the previous sub-block has been read out
     for (int e = tid; e < PKB * PKB * 9; e += 256) {
       const int r = e / (PKB * 9), c = e % (PKB * 9);
-      tile[r * PKP + c] = (co0 + r < d.Cout && c < ncol) ? d.w[((size_t)(co0 + r) * d.Cin + ci0) * 9 + c] * scale : 0.f;
+      tile[r * PKP + c] = (co0 + r < Cout && c < ncol) ? w[((size_t)(co0 + r) * Cin + ci0) * 9 + c] * scale : 0.f;
     }
     __syncthreads();
 #pragma unroll 2
@@ -1635,7 +1637,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restr
       w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2] * s_lo, lo[3] * s_lo, w_lo, true);
       const int k0 = o == 0 ? ci0 : co0, mm = (o == 0 ? co0 : ci0) + ml;
       const int nchunk = o == 0 ? nchunk0 : nchunk1, ncob = o == 0 ? ncob0 : ncob1;
-      unsigned char* t = (o == 0 ? d.wp_fwd : d.wp_bwd) + ((size_t)(tap * nchunk + (k0 >> 5)) * ncob + (mm >> 7)) * 16384;
+      unsigned char* t = (o == 0 ? wp_fwd : wp_bwd) + ((size_t)(tap * nchunk + (k0 >> 5)) * ncob + (mm >> 7)) * 16384;
       const int m_ = mm & 127, kk = k4 * 4;
       *reinterpret_cast<f16x4*>(t + (kk >> 3) * 2048 + m_ * 16 + (kk & 7) * 2) = hh;
       unsigned char* p8 = t + 8192 + ((kk >> 4) * 128 + m_) * 16 + (kk & 15);
@@ -1643,6 +1645,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restr
       *reinterpret_cast<int*>(p8 + 2 * 128 * 16) = w_lo;
     }
   }
+}
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ descs, float scale) {
+  const PackDesc d = descs[blockIdx.y];
+  pack_tiles_body(d.w, d.wp_fwd, d.wp_bwd, d.Cout, d.Cin, scale, pack_parts_of(d), PACK_MULTI_PARTS, blockIdx.x, gridDim.x);
+}
+// one layer, either or both orientations (eovae_conv3x3_f16c8_pack / _pack_pair)
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
+                                                         unsigned char* __restrict__ wp_bwd, int Cout, int Cin, float scale,
+                                                         const float* __restrict__ parts, int nparts) {
+  pack_tiles_body(w, wp_fwd, wp_bwd, Cout, Cin, scale, parts, nparts, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -1693,11 +1705,18 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
   if (ab > PACK_PARTS) ab = PACK_PARTS;
   if (ab < 1) ab = 1;
   hipLaunchKernelGGL(absmax_part_kernel, dim3((unsigned)ab), dim3(256), 0, st, w, nw, parts);
-  const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
-                     scale, (const float*)parts, (int)ab, hdr);
+  if (eovae_opt(EOVAE_OPT_C8_PACK_GATHER)) {   // the per-element gather kernel of rounds 2-3 (reference of the LDS-staged pack)
+    const size_t total = (size_t)9 * nchunk * ncob * 128 * 8;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
+                       scale, (const float*)parts, (int)ab, hdr);
+  } else {
+    int blocks = cdiv(Cout, 128) * 4 * cdiv(Cin, 128) * 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(blocks), dim3(256), 0, st, w, flip ? (unsigned char*)nullptr : base,
+                       flip ? base : (unsigned char*)nullptr, Cout, Cin, scale, (const float*)parts, (int)ab);
+  }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack");
   return EOVAE_OK;
 }
@@ -1728,8 +1747,14 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
     hipLaunchKernelGGL(pack_f16c8_kernel, dim3(blocks), dim3(256), 0, st, w, base, Cout, Cin, nchunk, ncob, flip,
                        scale, (const float*)parts, (int)ab, hdr);
   };
-  launch(b0, nch0, ncb0, 0, hdr0);
-  launch(b1, nch1, ncb1, 1, hdr1);
+  if (eovae_opt(EOVAE_OPT_C8_PACK_GATHER)) {
+    launch(b0, nch0, ncb0, 0, hdr0);
+    launch(b1, nch1, ncb1, 1, hdr1);
+  } else {   // both orientations from one coalesced read of the weights
+    int blocks = cdiv(Cout, 128) * 4 * cdiv(Cin, 128) * 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(blocks), dim3(256), 0, st, w, b0, b1, Cout, Cin, scale, (const float*)parts, (int)ab);
+  }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_pack_pair");
   return EOVAE_OK;
 }

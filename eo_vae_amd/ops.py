@@ -511,6 +511,19 @@ def _subpix_packed(weight, flip, f16c8=False):
     return _pack3x3(we, 4 * cout, cin, flip, f16c8)
 
 
+def _subpix_packed_pair(weight):
+    """(forward, data-gradient) f16c8 packs of the four parity kernels from ONE expansion and one read of it."""
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    we = torch.empty(4 * cout, cin, 3, 3, dtype=torch.float32, device=weight.device)
+    L.check(lib.eovae_subpix_expand(L.ptr(weight), L.ptr(we), cout, cin, L.stream()), 'eovae_subpix_expand')
+    wp0 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(4 * cout, cin, 0), dtype=torch.uint8, device=weight.device)
+    wp1 = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(4 * cout, cin, 1), dtype=torch.uint8, device=weight.device)
+    L.check(lib.eovae_conv3x3_f16c8_pack_pair(L.ptr(we), L.ptr(wp0), L.ptr(wp1), 4 * cout, cin, 1.0, L.stream()),
+            'eovae_conv3x3_f16c8_pack_pair')
+    return wp0, wp1
+
+
 def _down_ok(x, weight):
     cout, cin = weight.shape[0], weight.shape[1]
     return (SUBPIX_UPSAMPLE and CONV_PRECISION != 'f32' and cin % 128 == 0 and x.shape[2] % 2 == 0
@@ -567,11 +580,16 @@ def down_conv_s2d_wgrad(x, dy, weight, db=None, xamax=None):
     return dw
 
 
-def up_conv_subpix(x, weight, bias):
+def up_conv_subpix(x, weight, bias, want_bwd=False):
+    """want_bwd (f16c8): also returns the data-gradient pack made from the same expansion (else None)."""
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     f8 = _use_f16c8(cin)
-    wp = _subpix_packed(weight, False, f8)
+    wp_bwd = None
+    if want_bwd and f8 and _use_f16c8(cout):
+        wp, wp_bwd = _subpix_packed_pair(weight)
+    else:
+        wp = _subpix_packed(weight, False, f8)
     y = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
     timed = CONV3X3_TIMER is not None
     if timed:
@@ -585,14 +603,15 @@ def up_conv_subpix(x, weight, bias):
     _LAST_GN_SUMS = sums
     if timed:
         ev1.record()
-    return y
+    return (y, wp_bwd) if want_bwd else y
 
 
-def up_conv_subpix_dgrad(dy, weight, h, w):
+def up_conv_subpix_dgrad(dy, weight, h, w, wp=None):
     n, cout = dy.shape[0], dy.shape[1]
     cin = weight.shape[1]
     f8 = _use_f16c8(cout)
-    wp = _subpix_packed(weight, True, f8)
+    if wp is None:
+        wp = _subpix_packed(weight, True, f8)
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
     timed = CONV3X3_TIMER is not None
     if timed:
@@ -694,8 +713,12 @@ class Conv2dFn(torch.autograd.Function):
             raise L.EovaeError('conv2d: operand-record input (GroupNorm packed output) is only understood by the '
                                "plain 3x3 f16c8 convolution")
         ctx.packed = packed
+        ctx.wp_bwd = None
         if ks == 3 and m == MODE_UP and res is None and _subpix_ok(weight):
-            y = up_conv_subpix(x, weight, bias_c)
+            if ctx.needs_input_grad[0]:     # (y, data-gradient pack from the same expansion)
+                y, ctx.wp_bwd = up_conv_subpix(x, weight, bias_c, want_bwd=True)
+            else:
+                y = up_conv_subpix(x, weight, bias_c)
         elif ks == 3 and m == MODE_DOWN and res is None and _down_ok(x, weight):
             y = down_conv_s2d(x, weight, bias_c)
         elif (THIN_WGRAD and ks == 3 and m == MODE_NORMAL and res is None and CONV_PRECISION != 'f32' and
@@ -745,7 +768,7 @@ class Conv2dFn(torch.autograd.Function):
         subpix = ks == 3 and m == MODE_UP and not ctx.has_res and _subpix_ok(weight)
         s2d = ks == 3 and m == MODE_DOWN and not ctx.has_res and _down_ok(x, weight)
         if ctx.needs_input_grad[0] and subpix:
-            dx = up_conv_subpix_dgrad(dy, weight, h, w)
+            dx = up_conv_subpix_dgrad(dy, weight, h, w, wp=getattr(ctx, 'wp_bwd', None))
         elif ctx.needs_input_grad[0] and s2d:
             dx = down_conv_s2d_dgrad(dy, weight, h, w)
         elif ctx.needs_input_grad[0] and ks == 3 and CONV_PRECISION != 'f32':

@@ -346,6 +346,7 @@ def test_weight_prepack_equals_the_per_layer_packs():
             got0, got1 = ops.pack_pair_f16c8(w)            # served from the prepack
             assert got0.data_ptr() == pp.packs[w.data_ptr()][0].data_ptr()
         ops.WeightPrepack.release()
+        L.check(lib.eovae_set_option(b'c8_pack_gather', 1), 'set_option')   # reference: the per-element gather kernel
         for w in ws:
             co, ci = w.shape[0], w.shape[1]
             ref0, ref1 = ops.pack_pair_f16c8(w)            # the per-layer launches
@@ -355,7 +356,21 @@ def test_weight_prepack_equals_the_per_layer_packs():
             for flip, (ref, got) in enumerate(((ref0, got0), (ref1, got1))):
                 nb = lib.eovae_conv3x3_f16c8_packed_bytes(co, ci, flip) - 256 * 4 - 12   # tiles + the header word
                 assert torch.equal(ref[:nb], got[:nb]), (co, ci, flip)
+        # the per-layer entries on the LDS-staged kernel (round 4) write the same bytes as the gather kernel: pair, and each
+        # orientation alone (the expanded sub-pixel / space-to-depth weights are packed this way)
+        for w in ws:
+            co, ci = w.shape[0], w.shape[1]
+            L.check(lib.eovae_set_option(b'c8_pack_gather', 1), 'set_option')
+            ref0, ref1 = ops.pack_pair_f16c8(w)
+            L.check(lib.eovae_set_option(b'c8_pack_gather', 0), 'set_option')
+            got0, got1 = ops.pack_pair_f16c8(w)
+            one0, one1 = ops._pack3x3(w, co, ci, False, True), ops._pack3x3(w, co, ci, True, True)
+            torch.cuda.synchronize()
+            for flip, (ref, got, one) in enumerate(((ref0, got0, one0), (ref1, got1, one1))):
+                nb = lib.eovae_conv3x3_f16c8_packed_bytes(co, ci, flip) - 256 * 4 - 12
+                assert torch.equal(ref[:nb], got[:nb]) and torch.equal(ref[:nb], one[:nb]), (co, ci, flip)
     finally:
+        L.check(lib.eovae_set_option(b'c8_pack_gather', 0), 'set_option')
         ops.WeightPrepack.release()
     # a pack is handed out only for the tensor it was made from -- a view that shares offset 0 but not the
     # shape, or a weight edited in place after run(), falls through to the per-layer pack
