@@ -28,6 +28,28 @@ def get_1d_sincos_pos_embed_from_grid_torch(embed_dim: int, pos: torch.Tensor) -
     return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
 
 
+# The embedding of the wavelengths is a pure function of `wvs` (no parameters): ~11 tiny launches at the head of every
+# step for a [C, 256] matrix that only changes with the modality.  Kept per tensor OBJECT (strong reference, so the id cannot
+# be recycled) and `_version` (in-place edits), as the generator cache below; never for a tensor that requires grad.
+_SINCOS_CACHE: dict = {}
+
+
+def wavelength_embedding(embed_dim: int, wvs: torch.Tensor) -> torch.Tensor:
+    """get_1d_sincos_pos_embed_from_grid_torch(embed_dim, wvs * 1000) (dynamic_conv.py:466-468, 640-642), memoised."""
+    if wvs.requires_grad or torch.is_inference_mode_enabled():
+        return get_1d_sincos_pos_embed_from_grid_torch(embed_dim, wvs * 1000)
+    key = (id(wvs), embed_dim)
+    hit = _SINCOS_CACHE.get(key)
+    if hit is not None and hit[0] is wvs and hit[1] == wvs._version:
+        return hit[2]
+    with torch.no_grad():
+        emb = get_1d_sincos_pos_embed_from_grid_torch(embed_dim, wvs * 1000)
+    if len(_SINCOS_CACHE) >= 64:
+        _SINCOS_CACHE.clear()
+    _SINCOS_CACHE[key] = (wvs, wvs._version, emb)
+    return emb
+
+
 class FCResLayer(nn.Module):  # :336-366
     def __init__(self, linear_size: int = 128):
         super().__init__()
@@ -252,7 +274,7 @@ class _DynamicBase(nn.Module):
             if out is not None:
                 self._remember(('id', id(wvs)), (wvs, wvs._version, out))
                 return out
-        waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
+        waves = wavelength_embedding(self.wv_planes, wvs)
         # The 4-head, <= 142-token self-attention of the generator runs on the MATH path of SDPA (two batched
         # GEMMs + softmax): PyTorch's fused path on ROCm is aotriton, i.e. Triton-built kernels, which this
         # product does not put into its step (north_star: no Triton); at this size there is nothing to fuse.
