@@ -382,3 +382,23 @@ def test_batch_prep_host_logic_against_the_reference_collate(golden, monkeypatch
         out = prep(raw)
         assert out['modality'] == str(g[f'collate{seed}_modality'])
         assert (out['image'] - T(g[f'collate{seed}_image'])).abs().max().item() < 2e-5
+
+
+def test_wavelength_embedding_is_memoised_per_tensor_object():
+    """dynamic_conv.wavelength_embedding: the same tensor object hits, an in-place edit or another object misses, a tensor
+    that requires grad is never cached (reference: get_1d_sincos_pos_embed_from_grid_torch(D, wvs * 1000),
+    dynamic_conv.py:466-468)."""
+    from eo_vae_amd import dynamic_conv as DC
+    DC._SINCOS_CACHE.clear()
+    w = torch.tensor([0.665, 0.56, 0.49])
+    a = DC.wavelength_embedding(64, w)
+    assert DC.wavelength_embedding(64, w) is a
+    assert torch.equal(a, DC.get_1d_sincos_pos_embed_from_grid_torch(64, w * 1000))
+    w.mul_(2.0)                                           # in-place edit: _version moves
+    b = DC.wavelength_embedding(64, w)
+    assert b is not a and torch.equal(b, DC.get_1d_sincos_pos_embed_from_grid_torch(64, w * 1000))
+    w2 = w.clone()
+    assert DC.wavelength_embedding(64, w2) is not b       # another object, same values: its own entry
+    wg = torch.tensor([0.5, 0.6], requires_grad=True)
+    e = DC.wavelength_embedding(64, wg)
+    assert e.requires_grad and (id(wg), 64) not in DC._SINCOS_CACHE
