@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(256) void pack_multi_amax_kernel(const PackDesc* __
 }
 // Both orientations of a layer from ONE coalesced read of its weights.  The per-element gather of pack_f16c8_body reads
 // w[co][ci][tap] at a 36-byte stride per tap pass (9 passes over the tensor) and, for the flipped image, one cache line per
-// lane: 0.94 ms per step for the 84 M weights of the full model (profiles/r04w_step_timeline.txt), 0.7 TB/s.  Here a block
+// lane: 0.94 ms per step for the 84 M weights of the full model (the step timeline of the build before this kernel; after: 0.32 ms, profiles/r04w_step_timeline.txt), 0.7 TB/s.  Here a block
 // stages a 32 co x 32 ci x 9 tap sub-block in LDS (32 contiguous 1,152-byte rows) and writes the 9 x 2 tile pieces it
 // owns: 512-byte runs in the packed images.  Same arithmetic per element as pack_f16c8_body (bit-identical output).
 constexpr int PKB = 32, PKP = PKB * 9 + 1;
