@@ -485,12 +485,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C2{}, dnx);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma8(accR, A8[R1], b8, sc_a, sc_b);
+      // SP == 2 (stride-2 layer, operands swapped): the products (py, a) = (1, 1) and (px, b) = (1, 1) are no taps of that
+      // layer -- block-uniform / wave-uniform skips of their MFMAs (the fold never reads those tiles)
+      const bool useR = !(SP == 2 && py == 1), useB = !(SP == 2 && kx == 1 && pxw == 1);
+      if (useR && useB) mfma8(accR, A8[R1], b8, sc_a, sc_b);
       if constexpr (IT == 0) {
         __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
         if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
       }
-      mfma8(accK, A8[K], b8, sc_a, sc_b);
+      if (useB) mfma8(accK, A8[K], b8, sc_a, sc_b);
       if constexpr (IT == 0) {
         if (!(EOVAE_ROWS_ABL & 2)) {
           request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
@@ -507,8 +510,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C3{}, dnx);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma16(accR, A16[R1][0], b0);
-      mfma16(accK, A16[K][0], b0);
+      if (useR && useB) mfma16(accR, A16[R1][0], b0);
+      if (useB) mfma16(accK, A16[K][0], b0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT < 3) {
         constexpr int nkx = (IT + 1) >> 1, nci = (IT + 1) & 1;
@@ -517,8 +520,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         b8 = rtr8(xslot_of(std::integral_constant<int, (Q + 1) % 4>{}) + b8off);   // the next stage's first B fragment
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma16(accR, A16[R1][1], b1);
-      mfma16(accK, A16[K][1], b1);
+      if (useR && useB) mfma16(accR, A16[R1][1], b1);
+      if (useB) mfma16(accK, A16[K][1], b1);
       __builtin_amdgcn_sched_barrier(0);
       (void)XO8;
     });
@@ -638,6 +641,36 @@ __global__ __launch_bounds__(256) void wgrad_up_fold_kernel(const float* __restr
   dw[((size_t)co * Cin + ci) * 9 + tap] = s;
 }
 
+
+// The stride-2 layer (pad (0,1,0,1) + 3x3 stride 2, layers.py Downsample) through the SAME kernel with the operands' roles
+// swapped: dW[co][ci][KY][KX] = sum dY[co][Y][X] x[ci][2Y + KY][2X + KX] is the sub-pixel product G[p][a][b] with the HI-res
+// tensor x in dY's place and the low-res dY (as records) in X's place, transposed:
+//     G[p][a][b][ci][co] = sum x[ci][2y + py][2x + px] * dY[co][y + a - 1 + py][x + b - 1 + px],   KY = 2 - 2a - py, KX = 2 - 2b - px
+// (py, a) = (0, 1), (1, 0), (0, 0) give KY = 0, 1, 2; (1, 1) pairs x rows with no tap and is dropped here (7 of the 16 products
+// per pixel are not needed: the kernel runs them anyway, at 4.4 x the useful rate of the tile kernel's space-to-depth mode,
+// which multiplied 36 tap-parity products for 9).  part[(slab * 2 + py) * split + y][4 px + 2 a + b][128 ci][64 co].
+__global__ __launch_bounds__(256) void wgrad_down_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+                                                              int Cin, int ncob64, int split) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)9 * Cout * Cin) return;
+  const int tap = (int)(i % 9);
+  const int ci = (int)((i / 9) % Cin);
+  const int co = (int)(i / ((size_t)9 * Cin));
+  const int KY = tap / 3, KX = tap % 3;
+  const int py = KY == 1 ? 1 : 0, a_ = KY == 0 ? 1 : 0;
+  const int px = KX == 1 ? 1 : 0, b_ = KX == 0 ? 1 : 0;
+  const int slab = (ci >> 7) * ncob64 + (co >> 6);     // kernel's "cob" = 128 rows of ci, "cib" = 64 columns of co
+  const float* q = part + ((((size_t)slab * 2 + py) * split) * 8 + 4 * px + (2 * a_ + b_)) * (128 * 64) + (ci & 127) * 64 + (co & 63);
+  float s0 = 0.f, s1 = 0.f;
+  int y = 0;
+  for (; y + 1 < split; y += 2) {
+    s0 += q[(size_t)y * 8 * 128 * 64];
+    s1 += q[(size_t)(y + 1) * 8 * 128 * 64];
+  }
+  if (y < split) s0 += q[(size_t)y * 8 * 128 * 64];
+  dw[i] = s0 + s1;
+}
+
 }  // namespace
 
 bool eovae_c8_wgrad_rows_eligible(const WgCArgs& a) {
@@ -714,6 +747,50 @@ int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, flo
   hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, a.ncib,
                      a.split);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_up");
+  return EOVAE_OK;
+}
+
+// ---- the stride-2 layer through the same kernel, operands swapped (wgrad_down_fold_kernel)
+int eovae_conv3x3_f16c8_wgrad_down_eligible(int N, int Cin, int H, int W, int Cout) {   // H, W: the OUTPUT (low-res) grid
+  return eovae_conv3x3_f16c8_wgrad_up_eligible(N, Cout, H, W, Cin);
+}
+
+size_t eovae_conv3x3_f16c8_wgrad_down_workspace(int N, int Cin, int H, int W, int Cout) {
+  return eovae_conv3x3_f16c8_wgrad_up_workspace(N, Cout, H, W, Cin);
+}
+
+// Weight gradient of conv3x3_stride2(pad(x, (0,1,0,1))): x fp32 [N][Cin][2H][2W], dy fp32 [N][Cout][H][W] -> dw[Cout][Cin][3][3]
+// (written).  dyamax / xamax: absmax bits of dy / x (nullable).  No bias gradient here (eovae_bias_grad).
+int eovae_conv3x3_f16c8_wgrad_down(const float* x, const float* dy, float* dw, const unsigned* dyamax, const unsigned* xamax, int N,
+                                   int Cin, int H, int W, int Cout, void* ws, void* stream) {
+  EOVAE_CHECK_ARG(x && dy && dw && ws, "conv3x3_f16c8_wgrad_down: null pointer");
+  EOVAE_CHECK_ARG(eovae_conv3x3_f16c8_wgrad_down_eligible(N, Cin, H, W, Cout), "conv3x3_f16c8_wgrad_down: shape N=%d Cin=%d out %dx%d "
+                  "Cout=%d (Cin %% 128, Cout %% 64, W %% 32)", N, Cin, H, W, Cout);
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = H * W, pblocks = cdiv(HW, 256);
+  int* rec = (int*)ws;   // records of dy: the kernel's low-res "X" operand
+  hipLaunchKernelGGL(f16c8_records_kernel, dim3(N * (Cout / 8) * pblocks), dim3(256), 0, st, dy, dyamax, rec, Cout, HW, pblocks);
+  WgCArgs a;
+  a.x = reinterpret_cast<const float*>(rec); a.dy = x; a.dwp = nullptr; a.db = nullptr; a.dyamax = xamax; a.xamax = dyamax;
+  a.part = reinterpret_cast<float*>((char*)ws + ((size_t)N * Cout * HW * 4 + 255) / 256 * 256);
+  a.N = N; a.Cin = Cout; a.Hin = H; a.Win = W; a.Cout = Cin; a.Hout = 2 * H; a.Wout = 2 * W;
+  a.mode = MODE_NORMAL; a.subpix = 1; a.creal = 0; a.cpb = 1; a.xpacked = 1;
+  a.tiles_x = W / 32; a.tiles_y = H; a.ntiles = N * a.tiles_x * H;
+  a.ncib = Cout / 64; a.ncob_ = Cin / 128;
+  a.split = up_rows_split(Cout, Cin);
+  const int strips = N * a.tiles_x;
+  int nseg = 1;
+  while (strips * nseg < a.split && H % (2 * nseg) == 0 && H / (2 * nseg) >= 8) nseg *= 2;
+  a.nseg = nseg;
+  a.units = strips * nseg;
+  if (a.split > a.units) a.split = a.units;
+  const int nslab = 2 * a.ncib * a.ncob_;
+  a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<2>, dim3(nslab * a.split), dim3(512), 0, st, a);
+  const size_t total = (size_t)9 * Cout * Cin;
+  hipLaunchKernelGGL(wgrad_down_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, a.ncib,
+                     a.split);
+  EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_down");
   return EOVAE_OK;
 }
 

@@ -148,6 +148,15 @@ int eovae_conv3x3_f16c8_wgrad_up_eligible(int N, int Cin, int H, int W, int Cout
 size_t eovae_conv3x3_f16c8_wgrad_up_workspace(int N, int Cin, int H, int W, int Cout);
 int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, float* db, const unsigned* dyamax,
                                  const unsigned* xamax, int N, int Cin, int H, int W, int Cout, void* ws, void* stream);
+/* Weight gradient of the stride-2 layer conv3x3_s2(pad(x, (0,1,0,1))) (layers.py Downsample) through the same kernel with
+ * the operands' roles swapped (the hi-res x in dy's place, records of the low-res dy in x's place; 9 of the 16 sub-pixel
+ * products are taps of this layer, the fold drops the rest): x fp32 [N][Cin][2H][2W], dy fp32 [N][Cout][H][W] ->
+ * dw[Cout][Cin][3][3] (written, bit-reproducible).  eligible: Cin % 128 == 0, Cout % 64 == 0, W % 32 == 0 (H, W = output
+ * grid).  No bias gradient (eovae_bias_grad). */
+int eovae_conv3x3_f16c8_wgrad_down_eligible(int N, int Cin, int H, int W, int Cout);
+size_t eovae_conv3x3_f16c8_wgrad_down_workspace(int N, int Cin, int H, int W, int Cout);
+int eovae_conv3x3_f16c8_wgrad_down(const float* x, const float* dy, float* dw, const unsigned* dyamax, const unsigned* xamax,
+                                   int N, int Cin, int H, int W, int Cout, void* ws, void* stream);
 /* xpacked = 1 (both entries above): x is not fp32 NCHW but the f16c8 OPERAND-RECORD tensor written by
  * eovae_gn_silu_fwd_packed: [N][C/8][H][W] records of 32 bytes = { 8 x f16 y | 8 x e5m2 (y - f16(y)) * 2^12 |
  * 8 x e5m2 y } for channels 8g..8g+7 -- N*C*H*W dwords, the size of the fp32 activation it replaces.  The

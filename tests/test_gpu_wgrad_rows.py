@@ -120,3 +120,50 @@ def test_upsample_weight_gradient_rows(n, cin, cout, h, w):
         assert rel_err(b1, bref.grad) < 2e-6 and rel_err(bt, bref.grad) < 2e-6
     finally:
         ops.CONV_PRECISION, ops.UP_WGRAD_ROWS = old, keep
+
+
+DOWN_SHAPES = [  # n, cin, cout, h, w (hi-res input)
+    (2, 128, 128, 32, 64),    # one strip
+    (3, 128, 64, 24, 128),    # two strips, one 64-column block of co
+    (1, 256, 192, 40, 192),   # 2 ci blocks x 3 co blocks
+    (2, 512, 512, 16, 64),    # the model's 512-channel stride-2 layer at a small grid
+    (1, 128, 128, 18, 64),    # odd output height
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', DOWN_SHAPES)
+def test_stride2_weight_gradient_rows(n, cin, cout, h, w):
+    """Stride-2 layer (layers.py Downsample: pad (0,1,0,1) + 3x3 stride 2): the weight gradient through the sub-pixel
+    row-streaming kernel with swapped operands, against fp64 torch on the CPU and the tile kernel's space-to-depth mode;
+    bit-reproducible; the bias gradient comes from eovae_bias_grad."""
+    import torch.nn.functional as F
+    from eo_vae_amd import ops
+    x = (hashed((n, cin, h, w), 331, 1.0) * 3.0).cuda()
+    wt = hashed((cout, cin, 3, 3), 332, 1.0 / (cin * 9) ** 0.5).cuda()
+    b = hashed((cout,), 333, 0.1).cuda()
+    gy = hashed((n, cout, h // 2, w // 2), 334, 1e-3).cuda()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = ops.UP_WGRAD_ROWS
+
+    def run(rows):
+        ops.UP_WGRAD_ROWS = rows
+        wg, bg = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        ops.conv2d(xin, wg, bg, None, 'down').backward(gy)
+        torch.cuda.synchronize()
+        return wg.grad.clone(), bg.grad.clone()
+    try:
+        d1, b1 = run(True)
+        d2, _ = run(True)
+        t1, bt = run(False)
+        assert torch.equal(d1, d2)
+        xc = F.pad(x.cpu().double(), (0, 1, 0, 1))
+        wref = wt.cpu().double().requires_grad_(True)
+        bref = b.cpu().double().requires_grad_(True)
+        F.conv2d(xc, wref, bref, stride=2).backward(gy.cpu().double())
+        assert rel_err(d1, wref.grad) < 5e-5, rel_err(d1, wref.grad)
+        assert rel_err(t1, wref.grad) < 5e-5
+        assert rel_err(d1, t1) < 1e-5
+        assert rel_err(b1, bref.grad) < 2e-6 and rel_err(bt, bref.grad) < 2e-6
+    finally:
+        ops.CONV_PRECISION, ops.UP_WGRAD_ROWS = old, keep

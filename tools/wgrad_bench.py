@@ -61,3 +61,22 @@ if os.environ.get('WGRAD_BENCH_UP', '1') != '0':
         t0, t1 = best[False], best[True]
         print(f'up {cin:4d}->{cout:4d} @{hw:3d}^2 -> {2*hw}^2 wgrad (incl. amax, records, fold): tile {t0:7.3f} ms {flops/t0/1e9:6.1f} TF alg | '
               f'rows {t1:7.3f} ms {flops/t1/1e9:6.1f} TF alg ({flops*4/9/t1/1e9:5.1f} actual) | x{t0/t1:.3f} | rows vs tile {err:.1e}', flush=True)
+
+# stride-2 layers (hi-res input shapes): tile kernel's space-to-depth mode vs the swapped-operand row-streaming form
+if os.environ.get('WGRAD_BENCH_DOWN', '1') != '0':
+    for cin, cout, hw in [(128, 128, 256), (256, 256, 128), (512, 512, 64)]:
+        x = torch.randn(B, cin, hw, hw, device='cuda') * 2
+        dy = torch.randn(B, cout, hw // 2, hw // 2, device='cuda') * 1e-4
+        w = torch.randn(cout, cin, 3, 3, device='cuda')
+        flops = 2.0 * B * (hw // 2) * (hw // 2) * cin * cout * 9
+        best, res = {False: 1e9, True: 1e9}, {}
+        for rnd in range(3):
+            for v in (False, True):
+                ops.UP_WGRAD_ROWS = v
+                run = lambda: ops.down_conv_s2d_wgrad(x, dy, w, torch.zeros(cout, device='cuda'))
+                best[v] = min(best[v], timeit(run, 5))
+                res[v] = run().clone()
+        err = ((res[True] - res[False]).abs().max() / res[False].abs().max()).item()
+        t0, t1 = best[False], best[True]
+        print(f'down {cin:4d}->{cout:4d} @{hw:3d}^2 -> {hw//2}^2 wgrad (incl. amax, records, fold): tile {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | '
+              f'rows {t1:7.3f} ms {flops/t1/1e9:6.1f} TF | x{t0/t1:.3f} | rows vs tile {err:.1e}', flush=True)
