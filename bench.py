@@ -87,10 +87,12 @@ def wgrad_roofline(wtimer, peak, elapsed, prec):
     ms, flops, n = wtimer.totals()
     if n == 0 or ms <= 0:
         return None
-    kernel = {'f16c8': 'wgrad3x3_f16c8_rows_kernel (plain layers with record input: row streaming) + wgrad3x3_f16c8_kernel',
+    kernel = {'f16c8': 'wgrad3x3_f16c8_rows_kernel<0|1|2> (row streaming: plain layers with record input | x2-upsample layers, '
+                       'sub-pixel form | stride-2 layers, swapped operands; each incl. its records / fold launches) + '
+                       'wgrad3x3_f16c8_kernel (fp32-input plain layers)',
               'f32': 'conv_wgrad_kernel'}.get(prec, 'wgrad3x3_bf16_kernel')
     ach = flops / (ms * 1e-3)
-    return {'bound': 'mfma', 'kernel': kernel + ' (3x3 weight gradient incl. sub-pixel / space-to-depth forms)',
+    return {'bound': 'mfma', 'kernel': kernel + ' -- algorithmic flops as the reference executes each layer (9 taps on its output grid)',
             'achieved': round(ach / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'launches': n, 'achieved_per_launch_ms': round(ms / n, 4),
             'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
