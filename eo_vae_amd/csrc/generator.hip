@@ -2,12 +2,13 @@
 // 336-366: sin-cos embedding -> FCResLayer -> nn.TransformerEncoder (d 256, 4 heads, FFN 2048, GELU, post-norm) over
 // [128 weight tokens | C wavelength tokens | 1 bias token] -> fc_weight / fc_bias).
 //
-// The generators are < 0.3 GFLOP and cost a training step ~2.2 ms all the same (profiles/r04q_generator_cost.log): on
+// The generators are < 0.3 GFLOP and cost a training step ~1.5-2.2 ms all the same (profiles/r04q_generator_cost.log): on
 // library GEMMs + ATen glue they are ~330 launches of 7-10 us each, and the encoder's generator is the head (forward)
 // and the tail (backward) of every step, where nothing overlaps it.  Here the whole token matrix ([<= 160, 256]) is a
 // handful of small exact-fp32 kernels per layer whose epilogues carry the glue (bias, GELU and its derivative, residual,
-// split-K partial sums folded by the LayerNorm that follows), so a layer is 9 launches forward and ~22 backward and
-// no launch leaves the chip idle for longer than a few microseconds.
+// split-K partial sums folded by the LayerNorm that follows), so a layer is 9 launches forward and ~22 backward.
+// Measured: as fast as the library path in the step -- a dependent tiny launch costs >= 5 us of stream
+// time whatever it computes -- so this file buys ownership of the arithmetic (no BLAS library in the step), not time.
 //
 //   eovae_gen_gemm      C[b](m, n) = epi(alpha * sum_k A[b](m, k) * B[b](n, k))   strided, batched, optional split-K
 //   eovae_gen_ln_fwd    y = LayerNorm(sum of split-K partials + bias + residual); keeps x_hat and 1/sigma

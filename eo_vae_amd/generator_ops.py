@@ -1,8 +1,11 @@
 """autograd bindings of csrc/generator.hip: the transformer encoder layer and the Linear layers of the wavelength-
 conditioned weight generators (reference: modules/dynamic_conv.py:62-183, 336-366) as small exact-fp32 HIP kernels.
 
-One encoder layer is 9 launches forward and 21-22 backward (library GEMMs + ATen glue: 13 and ~35, each 2-3 x longer at
-132 rows); nothing here touches a BLAS library, so the product no longer changes PyTorch's process-wide BLAS preference."""
+One encoder layer is 9 launches forward and 21-22 backward (library GEMMs + ATen glue: 13 and ~35).  Device-busy time of a
+generator's forward + backward fell from 2.26 to 1.35 ms, the train step did not move: in the step every dependent tiny
+launch costs >= 5 us of stream time whatever it computes.  What this buys is ownership: nothing here
+touches a BLAS library, the generated kernels do not depend on which one PyTorch picked, and the product no longer
+changes PyTorch's process-wide BLAS preference."""
 from __future__ import annotations
 
 import ctypes as C
