@@ -1478,6 +1478,28 @@ __global__ void absmax_part_kernel(const float* __restrict__ x, size_t n, float*
   }
 }
 
+// An UPPER BOUND of max|y| from the (sum, sum of squares) per (image, channel group) that the producing convolution's
+// epilogue accumulated for the following GroupNorm: max|y| <= sqrt(max_g sum_g y^2).  Good enough for the range guard's
+// power-of-two pre-scale (which only has to keep |x| * scale inside f16 / e5m2; a bound that is 2^k too large costs k of
+// f16's ~27 spare binades below the amax) and costs one 512-value reduction instead of a pass over the tensor.
+__global__ __launch_bounds__(256) void amax_bound_kernel(const double* __restrict__ sums, int n, unsigned* __restrict__ out) {
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double q = sums[2 * (size_t)i + 1];
+    m = q > m ? q : m;                        // NaN never wins
+  }
+  m = wave_max_d(m);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+    float b = (float)sqrt(m);
+    b = b * 1.0000002f + 1e-30f;              // never below the true root after the two roundings
+    *out = (b < 3.0e38f) ? __builtin_bit_cast(unsigned, b) : 0x7f7fffffu;
+  }
+}
+
 __device__ __forceinline__ int cdiv_d(int a, int b) { return (a + b - 1) / b; }
 constexpr int PACK_PARTS = 256;   // amax partials kept behind the header of a packed weight buffer
 
@@ -1681,6 +1703,15 @@ int eovae_absmax_bits(const float* x, size_t n, unsigned* out_bits, void* stream
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out_bits);
   EOVAE_CHECK_LAUNCH("eovae_absmax_bits");
+  return EOVAE_OK;
+}
+
+// *out_bits = float bits of an upper bound of max|y| from y's GroupNorm accumulators sums[n_groups][2] (eovae_conv3x3_f16c8_fwd's
+// gn_sums): sqrt of the largest sum of squares.  For range pre-scales only (see amax_bound_kernel).
+int eovae_amax_bound_from_sums(const double* sums, int n_groups, unsigned* out_bits, void* stream) {
+  EOVAE_CHECK_ARG(sums && out_bits && n_groups > 0, "amax_bound_from_sums: bad argument");
+  hipLaunchKernelGGL(amax_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, n_groups, out_bits);
+  EOVAE_CHECK_LAUNCH("eovae_amax_bound_from_sums");
   return EOVAE_OK;
 }
 

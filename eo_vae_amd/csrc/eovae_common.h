@@ -66,3 +66,8 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}

@@ -71,6 +71,7 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_wgrad_down_eligible': (_i, [_i, _i, _i, _i, _i]),
     'eovae_conv3x3_f16c8_wgrad_down_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'eovae_conv3x3_f16c8_wgrad_down': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'eovae_amax_bound_from_sums': (_i, [_p, _i, _p, _p]),
     'eovae_gen_gemm': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + [_ll] * 8 + [_f, _i, _i, _ll, _p]),
     'eovae_gen_ln_fwd': (_i, [_p, _i, _ll, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     'eovae_gen_ln_bwd': (_i, [_p, _p, _i, _ll, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),

@@ -157,6 +157,10 @@ int eovae_conv3x3_f16c8_wgrad_down_eligible(int N, int Cin, int H, int W, int Co
 size_t eovae_conv3x3_f16c8_wgrad_down_workspace(int N, int Cin, int H, int W, int Cout);
 int eovae_conv3x3_f16c8_wgrad_down(const float* x, const float* dy, float* dw, const unsigned* dyamax, const unsigned* xamax,
                                    int N, int Cin, int H, int W, int Cout, void* ws, void* stream);
+/* Upper bound of max|y| (float bits) from y's GroupNorm accumulators sums[n_groups][2] as eovae_conv3x3_f16c8_fwd filled
+ * them: sqrt(max sum of squares).  For the range guard's power-of-two pre-scale of a layer that reads y un-normalised:
+ * one 512-value reduction instead of a pass over y. */
+int eovae_amax_bound_from_sums(const double* sums, int n_groups, unsigned* out_bits, void* stream);
 /* xpacked = 1 (both entries above): x is not fp32 NCHW but the f16c8 OPERAND-RECORD tensor written by
  * eovae_gn_silu_fwd_packed: [N][C/8][H][W] records of 32 bytes = { 8 x f16 y | 8 x e5m2 (y - f16(y)) * 2^12 |
  * 8 x e5m2 y } for channels 8g..8g+7 -- N*C*H*W dwords, the size of the fp32 activation it replaces.  The

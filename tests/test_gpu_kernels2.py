@@ -663,3 +663,37 @@ def test_epilogue_amax_equals_a_reduction_pass():
         torch.cuda.synchronize()
     finally:
         ops.CONV_PRECISION = old
+
+
+def test_range_guard_bound_from_groupnorm_sums():
+    """ops.range_amax: for a tensor that still carries its producer's GroupNorm accumulators the guard's scale comes from
+    sqrt(max sum of squares) -- an UPPER bound of max|x| (never below it, at most sqrt(group size) above), from a 512-value
+    reduction; the layer that consumes it gives the same result as with the exact maximum, within the arithmetic's error."""
+    from eo_vae_amd import ops
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = ops.AMAX_FROM_SUMS
+    try:
+        torch.manual_seed(4)
+        x = torch.randn(2, 128, 32, 64, device='cuda')
+        w = torch.randn(128, 128, 3, 3, device='cuda') / 34
+        b = torch.randn(128, device='cuda') * 0.1
+        res = torch.randn(2, 128, 32, 64, device='cuda') * 5
+        ops.AMAX_FROM_SUMS = True
+        y = ops.conv2d(x, w, b, res, 'normal')                       # tagged with its GroupNorm sums
+        assert ops.gn_sums_of(y, 32) is not None
+        bound = ops.range_amax(y)
+        exact = ops.absmax_bits(y)
+        bv, ev = bound.view(torch.float32).item(), exact.view(torch.float32).item()
+        assert ev <= bv <= ev * (4 * 32 * 64) ** 0.5 * 1.001, (ev, bv)
+        assert ops.range_amax(y) is bound                             # tagged: no second launch
+        wd = torch.randn(128, 128, 3, 3, device='cuda') / 34
+        down_b = ops.conv2d(y, wd, None, None, 'down')
+        ops.AMAX_FROM_SUMS = False
+        y2 = y.clone()                                                # no tags: exact maximum by a pass
+        down_e = ops.conv2d(y2, wd, None, None, 'down')
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(y.double().cpu(), (0, 1, 0, 1)), wd.double().cpu(), stride=2)
+        eb = ((down_b.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+        ee = ((down_e.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+        assert eb < 3e-5 and ee < 3e-5, (eb, ee)
+    finally:
+        ops.CONV_PRECISION, ops.AMAX_FROM_SUMS = old, keep
