@@ -588,14 +588,19 @@ def down_conv_s2d_dgrad(dy, weight, h, w):
     return dx
 
 
+def down_wgrad_rows(n, cin, h, w, cout):
+    """True when down_conv_s2d_wgrad takes the row-streaming form for this layer (x is [n, cin, h, w]); that form does
+    not produce the bias gradient (the caller leaves db to eovae_bias_grad)."""
+    return bool(CONV_PRECISION == 'f16c8' and UP_WGRAD_ROWS and h % 2 == 0 and w % 2 == 0
+                and L.load().eovae_conv3x3_f16c8_wgrad_down_eligible(n, cin, h // 2, w // 2, cout))
+
+
 def down_conv_s2d_wgrad(x, dy, weight, db=None, xamax=None):
-    """db: pre-zeroed [Cout], filled by the tile kernel's space-to-depth mode only; the row-streaming form leaves it alone
-    and sets down_conv_s2d_wgrad.filled_db = False (the caller then computes the bias gradient by eovae_bias_grad)."""
+    """db: pre-zeroed [Cout], filled by the tile kernel's space-to-depth mode only (see down_wgrad_rows)."""
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     lib = L.load()
-    if (CONV_PRECISION == 'f16c8' and UP_WGRAD_ROWS and h % 2 == 0 and w % 2 == 0
-            and lib.eovae_conv3x3_f16c8_wgrad_down_eligible(n, cin, h // 2, w // 2, cout)):
+    if down_wgrad_rows(n, cin, h, w, cout):
         if xamax is None:
             xamax = range_amax(x)
         timed = WGRAD3X3_TIMER is not None
@@ -608,9 +613,7 @@ def down_conv_s2d_wgrad(x, dy, weight, db=None, xamax=None):
                                                    h // 2, w // 2, cout, L.ptr(ws), L.stream()), 'eovae_conv3x3_f16c8_wgrad_down')
         if timed:
             ev1.record()
-        down_conv_s2d_wgrad.filled_db = False
         return dw
-    down_conv_s2d_wgrad.filled_db = True
     dwp = torch.zeros(9 * cout * 4 * cin, dtype=torch.float32, device=x.device)
     _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, h // 2, w // 2, MODE_NORMAL, 2, xamax=xamax)
     dw = torch.empty_like(weight)
@@ -852,11 +855,9 @@ class Conv2dFn(torch.autograd.Function):
                 db = zeros_small(cout, torch.float32, x.device)
             dw = up_conv_subpix_wgrad(x, dy, weight, db, getattr(ctx, 'x_amax', None))
         elif ctx.needs_input_grad[1] and s2d:
-            if want_db:
+            if want_db and not down_wgrad_rows(n, cin, h, w, cout):   # (the row-streaming form leaves db to eovae_bias_grad)
                 db = zeros_small(cout, torch.float32, x.device)
             dw = down_conv_s2d_wgrad(x, dy, weight, db, getattr(ctx, 'x_amax', None))
-            if not down_conv_s2d_wgrad.filled_db:
-                db = None                       # the row-streaming form leaves the bias gradient to eovae_bias_grad (below)
         elif ctx.needs_input_grad[1] and ks == 1 and CONV_PRECISION != 'f32':
             dw = conv1x1_lowp_wgrad(x, dy)
         elif (ctx.needs_input_grad[1] and WGRAD_DIRECT and ks == 3 and m == MODE_NORMAL and CONV_PRECISION == 'f16c8'

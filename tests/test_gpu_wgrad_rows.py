@@ -167,3 +167,48 @@ def test_stride2_weight_gradient_rows(n, cin, cout, h, w):
         assert rel_err(b1, bref.grad) < 2e-6 and rel_err(bt, bref.grad) < 2e-6
     finally:
         ops.CONV_PRECISION, ops.UP_WGRAD_ROWS = old, keep
+
+
+def test_up_and_down_entries_edge_cases():
+    """The C entries themselves: an all-zero dy gives exact zeros (and an untouched db accumulator), db = NULL is accepted,
+    xamax = NULL (no range pre-scale) agrees with the scaled call inside f16's range, ineligible shapes are refused."""
+    import ctypes as C
+    from eo_vae_amd import lib as L, ops
+    lib = L.load()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    try:
+        n, cin, cout, h, w = 2, 64, 128, 8, 32
+        x = hashed((n, cin, h, w), 341, 1.0).cuda()
+        dy = hashed((n, cout, 2 * h, 2 * w), 342, 1e-3).cuda()
+        ws = torch.empty(lib.eovae_conv3x3_f16c8_wgrad_up_workspace(n, cin, h, w, cout) // 4 + 64, device='cuda')
+        amax_dy, amax_x = ops.absmax_bits(dy), ops.absmax_bits(x)
+
+        def up(xx, dd, db, ax):
+            dw = torch.full((cout, cin, 3, 3), float('nan'), device='cuda')
+            L.check(lib.eovae_conv3x3_f16c8_wgrad_up(L.ptr(xx), L.ptr(dd), L.ptr(dw), L.ptr(db), L.ptr(ops.absmax_bits(dd)), L.ptr(ax),
+                                                     n, cin, h, w, cout, L.ptr(ws), L.stream()), 'up')
+            torch.cuda.synchronize()
+            return dw
+        db = torch.zeros(cout, device='cuda')
+        z = up(x, torch.zeros_like(dy), db, amax_x)
+        assert torch.count_nonzero(z) == 0 and torch.count_nonzero(db) == 0
+        a = up(x, dy, None, amax_x)                      # no bias gradient asked for
+        b = up(x, dy, None, None)                        # no pre-scale: |x| ~ 1 is inside f16's range
+        assert torch.isfinite(a).all() and rel_err(a, b) < 2e-5
+        assert lib.eovae_conv3x3_f16c8_wgrad_up_eligible(n, cin, h, 48, cout) == 0       # W % 32
+        assert lib.eovae_conv3x3_f16c8_wgrad_up_eligible(n, 32, h, w, cout) == 0         # Cin % 64
+        assert lib.eovae_conv3x3_f16c8_wgrad_up(L.ptr(x), L.ptr(dy), L.ptr(a), None, L.ptr(amax_dy), None, n, 32, h, w, cout,
+                                                L.ptr(ws), L.stream()) != 0
+        # stride-2 entry: x hi-res [n, 128, 16, 64], dy [n, 64, 8, 32]
+        ci2, co2 = 128, 64
+        x2 = hashed((n, ci2, 2 * h, 2 * w), 343, 1.0).cuda()
+        dy2 = hashed((n, co2, h, w), 344, 1e-3).cuda()
+        ws2 = torch.empty(lib.eovae_conv3x3_f16c8_wgrad_down_workspace(n, ci2, h, w, co2) // 4 + 64, device='cuda')
+        dw2 = torch.full((co2, ci2, 3, 3), float('nan'), device='cuda')
+        L.check(lib.eovae_conv3x3_f16c8_wgrad_down(L.ptr(x2), L.ptr(torch.zeros_like(dy2)), L.ptr(dw2), L.ptr(ops.absmax_bits(dy2)),
+                                                   L.ptr(ops.absmax_bits(x2)), n, ci2, h, w, co2, L.ptr(ws2), L.stream()), 'down')
+        torch.cuda.synchronize()
+        assert torch.count_nonzero(dw2) == 0
+        assert lib.eovae_conv3x3_f16c8_wgrad_down_eligible(n, 64, h, w, co2) == 0        # Cin % 128
+    finally:
+        ops.CONV_PRECISION = old
