@@ -1418,23 +1418,27 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_kernel(WgCArgs a) {
 
 // dw[Cout][Cin][3][3] (PyTorch layout) = sum over the `split` partial tiles of each (co-block, ci-block) slab, in a
 // fixed order: deterministic, and the unpack step is gone.  One thread per (co, ci, tap).
-__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+// One block = one slab x ONE co row: 9 waves, wave = tap, lane = ci; every read is a 256-byte run of a partial tile, the sums
+// pass through LDS and leave as one 2,304-byte run of dw[co][ci0 .. ci0 + 63][tap] (a thread per output wrote 4 bytes of
+// each 32-byte sector at a time, eight visits per sector spread over the launch).  Same summation order per output.
+__global__ __launch_bounds__(576) void wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
                                                          int Cin, int ncib, int split) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)9 * Cout * Cin) return;
-  const int ci = (int)(i % Cin);
-  const int co = (int)((i / Cin) % Cout);
-  const int tap = (int)(i / ((size_t)Cin * Cout));
-  const int slab = (co >> 7) * ncib + (ci >> 6);
-  const float* p = part + (((size_t)slab * split) * 9 + tap) * (128 * 64) + (co & 127) * 64 + (ci & 63);
+  __shared__ float t[64 * 9];
+  const int slab = blockIdx.x >> 7, col = blockIdx.x & 127;
+  const int cob = slab / ncib, cib = slab % ncib;
+  const int tap = threadIdx.x >> 6, cil = threadIdx.x & 63;
+  const float* q = part + (((size_t)slab * split) * 9 + tap) * (128 * 64) + col * 64 + cil;
   float s0 = 0.f, s1 = 0.f;
   int y = 0;
   for (; y + 1 < split; y += 2) {
-    s0 += p[(size_t)y * 9 * 128 * 64];
-    s1 += p[(size_t)(y + 1) * 9 * 128 * 64];
+    s0 += q[(size_t)y * 9 * 128 * 64];
+    s1 += q[(size_t)(y + 1) * 9 * 128 * 64];
   }
-  if (y < split) s0 += p[(size_t)y * 9 * 128 * 64];
-  dw[((size_t)co * Cin + ci) * 9 + tap] = s0 + s1;
+  if (y < split) s0 += q[(size_t)y * 9 * 128 * 64];
+  t[cil * 9 + tap] = s0 + s1;
+  __syncthreads();
+  const int oc = cob * 128 + col, k = threadIdx.x, ic = cib * 64 + k / 9;
+  if (oc < Cout && ic < Cin) dw[((size_t)oc * Cin + cib * 64) * 9 + k] = t[k];
 }
 
 
@@ -2011,9 +2015,7 @@ static int c8_wgrad_impl(const float* x, const float* dy, float* dwp, float* par
   else if (xpacked) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, true>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<0, false>), grid, dim3(512), 0, st, a);
   if (part) {
-    const size_t total = (size_t)9 * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, dw, Cout, Cin, a.ncib,
-                       split);
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(a.ncib * ncob * 128)), dim3(576), 0, st, part, dw, Cout, Cin, a.ncib, split);
   }
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad");
   return EOVAE_OK;

@@ -613,22 +613,21 @@ __global__ __launch_bounds__(256) void f16c8_records_kernel(const float* __restr
 // tap (KY, KX) of the layer's kernel lands on (a, b) = (KY + py - 1 >= 1 ? .. ) of parity (py, px):
 //   py = 0: KY = 0 -> a = 0, KY = 1, 2 -> a = 1;   py = 1: KY = 0, 1 -> a = 0, KY = 2 -> a = 1   (same for KX, px, b).
 // Splits and parities are summed in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_up_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+__global__ __launch_bounds__(576) void wgrad_up_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
                                                             int Cin, int ncib, int split) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)9 * Cout * Cin) return;
-  const int ci = (int)(i % Cin);
-  const int co = (int)((i / Cin) % Cout);
-  const int tap = (int)(i / ((size_t)Cin * Cout));
+  // block = one slab x one co row, wave = tap, lane = ci: 256-byte reads of the parity tiles, one 2,304-byte run of dw (LDS)
+  __shared__ float t[64 * 9];
+  const int slab = blockIdx.x >> 7, col = blockIdx.x & 127;
+  const int cob = slab / ncib, cib = slab % ncib;
+  const int tap = threadIdx.x >> 6, cil = threadIdx.x & 63;
   const int KY = tap / 3, KX = tap % 3;
-  const int slab = (co >> 7) * ncib + (ci >> 6);
   float s = 0.f;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int py = p >> 1, px = p & 1;
     const int a_ = py == 0 ? (KY == 0 ? 0 : 1) : (KY == 2 ? 1 : 0);
     const int b_ = px == 0 ? (KX == 0 ? 0 : 1) : (KX == 2 ? 1 : 0);
-    const float* q = part + ((((size_t)slab * 2 + py) * split) * 8 + 4 * px + (2 * a_ + b_)) * (128 * 64) + (co & 127) * 64 + (ci & 63);
+    const float* q = part + ((((size_t)slab * 2 + py) * split) * 8 + 4 * px + (2 * a_ + b_)) * (128 * 64) + col * 64 + cil;
     float s0 = 0.f, s1 = 0.f;
     int y = 0;
     for (; y + 1 < split; y += 2) {
@@ -638,7 +637,10 @@ __global__ __launch_bounds__(256) void wgrad_up_fold_kernel(const float* __restr
     if (y < split) s0 += q[(size_t)y * 8 * 128 * 64];
     s += s0 + s1;
   }
-  dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+  t[cil * 9 + tap] = s;
+  __syncthreads();
+  const int oc = cob * 128 + col, k = threadIdx.x, ic = cib * 64 + k / 9;
+  if (oc < Cout && ic < Cin) dw[((size_t)oc * Cin + cib * 64) * 9 + k] = t[k];
 }
 
 
@@ -649,26 +651,36 @@ __global__ __launch_bounds__(256) void wgrad_up_fold_kernel(const float* __restr
 // (py, a) = (0, 1), (1, 0), (0, 0) give KY = 0, 1, 2; (1, 1) pairs x rows with no tap and is dropped here (7 of the 16 products
 // per pixel are not needed: the kernel runs them anyway, at 4.4 x the useful rate of the tile kernel's space-to-depth mode,
 // which multiplied 36 tap-parity products for 9).  part[(slab * 2 + py) * split + y][4 px + 2 a + b][128 ci][64 co].
-__global__ __launch_bounds__(256) void wgrad_down_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+__global__ __launch_bounds__(576) void wgrad_down_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout,
                                                               int Cin, int ncob64, int split) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)9 * Cout * Cin) return;
-  const int tap = (int)(i % 9);
-  const int ci = (int)((i / 9) % Cin);
-  const int co = (int)(i / ((size_t)9 * Cin));
+  // block = one slab (128 ci x 64 co) x four ci rows, wave = tap, lane = co (the tiles' columns: 256-byte reads); dw wants
+  // (ci, tap) runs per co: 4 ci x 9 taps = 144 bytes each, through LDS
+  __shared__ float t[64][4 * 9 + 1];
+  const int slab = blockIdx.x >> 5, g4 = blockIdx.x & 31;
+  const int cib128 = slab / ncob64, cob64 = slab % ncob64;     // kernel's "cob" = 128 rows of ci, "cib" = 64 columns of co
+  const int tap = threadIdx.x >> 6, col = threadIdx.x & 63;
   const int KY = tap / 3, KX = tap % 3;
   const int py = KY == 1 ? 1 : 0, a_ = KY == 0 ? 1 : 0;
   const int px = KX == 1 ? 1 : 0, b_ = KX == 0 ? 1 : 0;
-  const int slab = (ci >> 7) * ncob64 + (co >> 6);     // kernel's "cob" = 128 rows of ci, "cib" = 64 columns of co
-  const float* q = part + ((((size_t)slab * 2 + py) * split) * 8 + 4 * px + (2 * a_ + b_)) * (128 * 64) + (ci & 127) * 64 + (co & 63);
-  float s0 = 0.f, s1 = 0.f;
-  int y = 0;
-  for (; y + 1 < split; y += 2) {
-    s0 += q[(size_t)y * 8 * 128 * 64];
-    s1 += q[(size_t)(y + 1) * 8 * 128 * 64];
+#pragma unroll
+  for (int cr = 0; cr < 4; ++cr) {
+    const int row = g4 * 4 + cr;                               // ci row of the tile
+    const float* q = part + ((((size_t)slab * 2 + py) * split) * 8 + 4 * px + (2 * a_ + b_)) * (128 * 64) + row * 64 + col;
+    float s0 = 0.f, s1 = 0.f;
+    int y = 0;
+    for (; y + 1 < split; y += 2) {
+      s0 += q[(size_t)y * 8 * 128 * 64];
+      s1 += q[(size_t)(y + 1) * 8 * 128 * 64];
+    }
+    if (y < split) s0 += q[(size_t)y * 8 * 128 * 64];
+    t[col][cr * 9 + tap] = s0 + s1;
   }
-  if (y < split) s0 += q[(size_t)y * 8 * 128 * 64];
-  dw[i] = s0 + s1;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 36; e += 576) {
+    const int c = e / 36, k = e % 36;
+    const int oc = cob64 * 64 + c, ic = cib128 * 128 + g4 * 4 + k / 9;
+    if (oc < Cout && ic < Cin) dw[((size_t)oc * Cin + cib128 * 128 + g4 * 4) * 9 + k] = t[c][k];
+  }
 }
 
 }  // namespace
@@ -743,8 +755,7 @@ int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, flo
   const int nslab = 2 * a.ncib * a.ncob_;
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<1>, dim3(nslab * a.split), dim3(512), 0, st, a);
-  const size_t total = (size_t)9 * Cout * Cin;
-  hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, a.ncib,
+  hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)(a.ncib * a.ncob_ * 128)), dim3(576), 0, st, a.part, dw, Cout, Cin, a.ncib,
                      a.split);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_up");
   return EOVAE_OK;
@@ -787,8 +798,7 @@ int eovae_conv3x3_f16c8_wgrad_down(const float* x, const float* dy, float* dw, c
   const int nslab = 2 * a.ncib * a.ncob_;
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<2>, dim3(nslab * a.split), dim3(512), 0, st, a);
-  const size_t total = (size_t)9 * Cout * Cin;
-  hipLaunchKernelGGL(wgrad_down_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, a.ncib,
+  hipLaunchKernelGGL(wgrad_down_fold_kernel, dim3((unsigned)(a.ncib * a.ncob_ * 32)), dim3(576), 0, st, a.part, dw, Cout, Cin, a.ncib,
                      a.split);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_down");
   return EOVAE_OK;
