@@ -339,6 +339,12 @@ def main():
     from eo_vae_amd.dynamic_conv import prefer_rocblas_for_generator
     from eo_vae_amd.parallel import init_distributed
     blas_backend = prefer_rocblas_for_generator()   # this process is the benchmark's own
+    timing_only = None
+    if os.environ.get('EOVAE_TIMING_FREEZE_GENERATORS') == '1':    # what the hyper-networks cost a step: an INVALID line, marked so
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+        import generator_freeze
+        generator_freeze.install()
+        timing_only = 'weight generators frozen (no generator gradients): NOT a valid benchmark line'
 
     rank, world, local = init_distributed()
     if world != args.gpus and not (world == 1 and args.gpus == 1):
@@ -496,6 +502,8 @@ def main():
             'hbm_roofline_frac': round(ips / world / r_hbm, 4),
             'final_loss': final_loss,
         }
+        if timing_only:
+            out['timing_only'] = timing_only
         if args.workload == 'cfg5':
             out['metric'] = 'encode-only images/sec (BxCx256x256)'
             out.pop('hbm_roofline_frac', None)

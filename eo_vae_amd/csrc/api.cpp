@@ -28,6 +28,7 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
     {"c8_w4_skew", "EOVAE_C8_W4_SKEW", -1},
     {"c8_wgrad_w4", "EOVAE_C8_WGRAD_W4", 0},       // conv_f16c8_wgrad_w4.hip (parked: slower than the 8-wave kernels)
     {"c8_pack_gather", "EOVAE_C8_PACK_GATHER", 0}, // per-layer weight packs by the per-element gather kernel (reference of the LDS-staged one)
+    {"c8_mx", "EOVAE_C8_MX", 1},                   // MX-FP6 correction product (conv_f16c8_common.h); 0 = the fp8 form everywhere
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -69,6 +70,6 @@ int eovae_get_option(const char* name) {
   eovae_set_error("eovae_get_option: unknown option '%s'", name ? name : "(null)");
   return EOVAE_ERR_ARG;
 }
-int eovae_abi_version(void) { return 10; }  // 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option; 10: eovae_gen_* (weight generators)
+int eovae_abi_version(void) { return 11; }  // 11: MX-FP6 correction product (eovae_gn_silu_fwd_packed_mx, eovae_conv3x3_f16c8_fwd_mx, 24 KiB weight tiles); 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option; 10: eovae_gen_* (weight generators)
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

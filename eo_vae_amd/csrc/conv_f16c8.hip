@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
   constexpr int NI = TH / (NW / 2);             // pixel-row tiles per wave
   constexpr int XF16 = 4 * NPX * 16;            // f16 image: [octet][pixel][8 ch]
   constexpr int XSET = 8 * NPX * 16;            // + fp8 images [lo'|hi'][half][pixel][16 B]
-  constexpr int WTAP = 16384, WF16 = 8192;
+  constexpr int WTAP = 16384, WF16 = 8192;   // LDS slot of one tap: the f16 + fp8 parts of its C8_WTILE-byte tile
   // two halo buffers where they fit beside the 4-slot weight ring (8-row tile: 2 x 42.5 + 64 KiB): the staged
   // chunk is converted straight into the other buffer, no barrier pair and no packed copy in registers
   constexpr bool XDB = 2 * XSET + 4 * WTAP <= 160 * 1024;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       xinv = pow2f(e - 13);
     }
   }
-  const unsigned wbits = *reinterpret_cast<const unsigned*>(a.wp + (size_t)9 * a.nchunk * a.ncob * WTAP);
+  const unsigned wbits = *reinterpret_cast<const unsigned*>(a.wp + (size_t)9 * a.nchunk * a.ncob * C8_WTILE);
   const int e1 = wbits ? 7 - expo_of_bits(wbits) : 0;   // amax(w) * 2^e1 in [128, 256)
   auto e8m0 = [](int k) { k += 127; return k < 0 ? 0 : (k > 254 ? 254 : k); };
   // K-block 0 (lanes h = 0): xl' * wh' = 2^12 xl * 2^e1 w    K-block 1 (h = 1): xh' * wl' = x * 2^(e1+12) wl:
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
     for (int tt = 0; tt < 2; ++tt) {
       int ky, kx;
       tap_of(t, chunk, t0 + tt, ky, kx);
-      const unsigned char* src = a.wp + ((size_t)((ky * 3 + kx) * a.nchunk + chunk) * a.ncob + t.cob) * WTAP;
+      const unsigned char* src = a.wp + ((size_t)((ky * 3 + kx) * a.nchunk + chunk) * a.ncob + t.cob) * C8_WTILE;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int piece = (wave * 2 + u) * 1024;
@@ -1558,12 +1558,41 @@ __device__ __forceinline__ void pack_f16c8_body(const float* __restrict__ w, uns
     w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * s_hi, v[3] * s_hi, w_hi, true);
     int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0] * s_lo, lo[1] * s_lo, 0, false);
     w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2] * s_lo, lo[3] * s_lo, w_lo, true);
-    unsigned char* tile = wp + ((size_t)(tap * nchunk + chunk) * ncob + cob) * 16384;
+    unsigned char* tile = wp + ((size_t)(tap * nchunk + chunk) * ncob + cob) * C8_WTILE;
     const int kk = k4 * 4;   // first k of this thread inside the chunk
     *reinterpret_cast<f16x4*>(tile + (kk >> 3) * 2048 + m_ * 16 + (kk & 7) * 2) = hh;
     unsigned char* p8 = tile + 8192 + ((kk >> 4) * 128 + m_) * 16 + (kk & 15);
     *reinterpret_cast<int*>(p8) = w_hi;
     *reinterpret_cast<int*>(p8 + 2 * 128 * 16) = w_lo;
+  }
+  // MX-FP6 part of every tile (conv_f16c8_common.h): one thread = one (tile, row m), both operands
+  const size_t rows = (size_t)9 * nchunk * ncob * 128;
+  for (size_t i = bid * (size_t)blockDim.x + threadIdx.x; i < rows; i += (size_t)nblk * blockDim.x) {
+    const int m_ = i & 127;
+    size_t t = i >> 7;
+    const int cob = t % ncob;
+    t /= ncob;
+    const int chunk = t % nchunk;
+    const int tap = t / nchunk;
+    const int st = flip ? 8 - tap : tap;
+    float v[32], lo[32], ah = 0.f, al = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int k = chunk * 32 + j, m = cob * 128 + m_;
+      const int co = flip ? k : m, ci = flip ? m : k;
+      v[j] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + st] * scale : 0.f;
+      lo[j] = v[j] - (float)(_Float16)v[j];
+      ah = fmaxf(ah, fabsf(v[j]));
+      al = fmaxf(al, fabsf(lo[j]));
+    }
+    i32x4 q0, q1;
+    unsigned char* p6 = wp + ((size_t)(tap * nchunk + chunk) * ncob + cob) * C8_WTILE + C8_WOFF6 + m_ * 16;
+    mx6_quant(v, ah, q0, q1);                       // wh6: pairs with the activations' residual part
+    *reinterpret_cast<i32x4*>(p6) = q0;
+    *reinterpret_cast<i32x4*>(p6 + 128 * 16) = q1;
+    mx6_quant(lo, al, q0, q1);                      // wl6: pairs with the activations' leading part
+    *reinterpret_cast<i32x4*>(p6 + 2 * 128 * 16) = q0;
+    *reinterpret_cast<i32x4*>(p6 + 3 * 128 * 16) = q1;
   }
 }
 
@@ -1583,7 +1612,7 @@ struct PackDesc {
 };
 constexpr int PACK_MULTI_PARTS = 64;
 __device__ __forceinline__ float* pack_parts_of(const PackDesc& d) {   // behind the header of the forward buffer
-  return reinterpret_cast<float*>(d.wp_fwd + (size_t)9 * cdiv_d(d.Cin, 32) * cdiv_d(d.Cout, 128) * 16384 + 16);
+  return reinterpret_cast<float*>(d.wp_fwd + (size_t)9 * cdiv_d(d.Cin, 32) * cdiv_d(d.Cout, 128) * C8_WTILE + 16);
 }
 __global__ __launch_bounds__(256) void pack_multi_amax_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
@@ -1624,8 +1653,8 @@ __device__ __forceinline__ void pack_tiles_body(const float* __restrict__ w, uns
   const int nchunk1 = cdiv_d(Cout, 32), ncob1 = cdiv_d(Cin, 128);
   if (bid == 0 && tid == 0) {
     const unsigned wbits = __builtin_bit_cast(unsigned, wmax);
-    if (wp_fwd) *reinterpret_cast<unsigned*>(wp_fwd + (size_t)9 * nchunk0 * ncob0 * 16384) = wbits;
-    if (wp_bwd) *reinterpret_cast<unsigned*>(wp_bwd + (size_t)9 * nchunk1 * ncob1 * 16384) = wbits;
+    if (wp_fwd) *reinterpret_cast<unsigned*>(wp_fwd + (size_t)9 * nchunk0 * ncob0 * C8_WTILE) = wbits;
+    if (wp_bwd) *reinterpret_cast<unsigned*>(wp_bwd + (size_t)9 * nchunk1 * ncob1 * C8_WTILE) = wbits;
   }
   const float amax = wmax * fabsf(scale);
   const int e1 = amax > 0.f ? 7 - expo_of_bits(__builtin_bit_cast(unsigned, amax)) : 0;
@@ -1663,12 +1692,37 @@ __device__ __forceinline__ void pack_tiles_body(const float* __restrict__ w, uns
       w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2] * s_lo, lo[3] * s_lo, w_lo, true);
       const int k0 = o == 0 ? ci0 : co0, mm = (o == 0 ? co0 : ci0) + ml;
       const int nchunk = o == 0 ? nchunk0 : nchunk1, ncob = o == 0 ? ncob0 : ncob1;
-      unsigned char* t = (o == 0 ? wp_fwd : wp_bwd) + ((size_t)(tap * nchunk + (k0 >> 5)) * ncob + (mm >> 7)) * 16384;
+      unsigned char* t = (o == 0 ? wp_fwd : wp_bwd) + ((size_t)(tap * nchunk + (k0 >> 5)) * ncob + (mm >> 7)) * C8_WTILE;
       const int m_ = mm & 127, kk = k4 * 4;
       *reinterpret_cast<f16x4*>(t + (kk >> 3) * 2048 + m_ * 16 + (kk & 7) * 2) = hh;
       unsigned char* p8 = t + 8192 + ((kk >> 4) * 128 + m_) * 16 + (kk & 15);
       *reinterpret_cast<int*>(p8) = w_hi;
       *reinterpret_cast<int*>(p8 + 2 * 128 * 16) = w_lo;
+    }
+    // MX-FP6 part (conv_f16c8_common.h): a thread takes one (orientation, tap, row) with all 32 k of the sub-block --
+    // 576 tasks; lanes differ in the row, i.e. by PKP (orientation 0) or 9 (orientation 1) floats: conflict-free
+    for (int task = tid; task < 2 * 9 * PKB; task += 256) {
+      const int o = task / (9 * PKB), tap = (task / PKB) % 9, ml = task % PKB;
+      if (o == 0 ? !fwd : !bwd) continue;
+      float v[32], lo[32], ah = 0.f, al = 0.f;
+#pragma unroll
+      for (int kl = 0; kl < 32; ++kl) {
+        v[kl] = o == 0 ? tile[ml * PKP + kl * 9 + tap] : tile[kl * PKP + ml * 9 + (8 - tap)];
+        lo[kl] = v[kl] - (float)(_Float16)v[kl];
+        ah = fmaxf(ah, fabsf(v[kl]));
+        al = fmaxf(al, fabsf(lo[kl]));
+      }
+      const int k0 = o == 0 ? ci0 : co0, mm = (o == 0 ? co0 : ci0) + ml;
+      const int nchunk = o == 0 ? nchunk0 : nchunk1, ncob = o == 0 ? ncob0 : ncob1;
+      unsigned char* p6 = (o == 0 ? wp_fwd : wp_bwd) + ((size_t)(tap * nchunk + (k0 >> 5)) * ncob + (mm >> 7)) * C8_WTILE +
+                          C8_WOFF6 + (mm & 127) * 16;
+      i32x4 q0, q1;
+      mx6_quant(v, ah, q0, q1);
+      *reinterpret_cast<i32x4*>(p6) = q0;
+      *reinterpret_cast<i32x4*>(p6 + 128 * 16) = q1;
+      mx6_quant(lo, al, q0, q1);
+      *reinterpret_cast<i32x4*>(p6 + 2 * 128 * 16) = q0;
+      *reinterpret_cast<i32x4*>(p6 + 3 * 128 * 16) = q1;
     }
   }
 }
@@ -1723,7 +1777,7 @@ int eovae_amax_bound_from_sums(const double* sums, int n_groups, unsigned* out_b
 // the amax partials of the pack call)
 size_t eovae_conv3x3_f16c8_packed_bytes(int Cout, int Cin, int flip) {
   const int k = flip ? Cout : Cin, m = flip ? Cin : Cout;
-  return (size_t)9 * cdiv(k, 32) * cdiv(m, 128) * 16384 + 16 + PACK_PARTS * sizeof(float);
+  return (size_t)9 * cdiv(k, 32) * cdiv(m, 128) * C8_WTILE + 16 + PACK_PARTS * sizeof(float);
 }
 
 int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int flip, float scale, void* stream) {
@@ -1731,7 +1785,7 @@ int eovae_conv3x3_f16c8_pack(const float* w, void* wp, int Cout, int Cin, int fl
   const int k = flip ? Cout : Cin, m = flip ? Cin : Cout;
   const int nchunk = cdiv(k, 32), ncob = cdiv(m, 128);
   unsigned char* base = (unsigned char*)wp;
-  unsigned* hdr = (unsigned*)(base + (size_t)9 * nchunk * ncob * 16384);
+  unsigned* hdr = (unsigned*)(base + (size_t)9 * nchunk * ncob * C8_WTILE);
   float* parts = (float*)(hdr + 4);
   hipStream_t st = (hipStream_t)stream;
   EOVAE_CHECK_ARG(((uintptr_t)w & 15) == 0, "conv3x3_f16c8_pack: w must be 16-byte aligned");
@@ -1766,8 +1820,8 @@ int eovae_conv3x3_f16c8_pack_pair(const float* w, void* wp_fwd, void* wp_bwd, in
   unsigned char* b0 = (unsigned char*)wp_fwd;
   unsigned char* b1 = (unsigned char*)wp_bwd;
   const int nch0 = cdiv(Cin, 32), ncb0 = cdiv(Cout, 128), nch1 = cdiv(Cout, 32), ncb1 = cdiv(Cin, 128);
-  unsigned* hdr0 = (unsigned*)(b0 + (size_t)9 * nch0 * ncb0 * 16384);
-  unsigned* hdr1 = (unsigned*)(b1 + (size_t)9 * nch1 * ncb1 * 16384);
+  unsigned* hdr0 = (unsigned*)(b0 + (size_t)9 * nch0 * ncb0 * C8_WTILE);
+  unsigned* hdr1 = (unsigned*)(b1 + (size_t)9 * nch1 * ncb1 * C8_WTILE);
   EOVAE_CHECK_ARG(((uintptr_t)w & 15) == 0, "conv3x3_f16c8_pack_pair: w must be 16-byte aligned");
   float* parts = (float*)(hdr0 + 4);
   const size_t nw = (size_t)Cout * Cin * 9;
@@ -1828,7 +1882,7 @@ int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Ho
                               int xpacked) {
   ConvCArgs a;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout; a.mode = mode;
-  a.packed = xpacked;
+  a.packed = xpacked; a.x6 = nullptr; a.mx = 0;
   const int n_cu = c8_n_cu();
   return (n_cu > 0 && subpix == 0 && eovae_c8_w4_eligible(a, subpix, n_cu)) ? 1 : 0;
 }
@@ -1841,12 +1895,17 @@ int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bi
                                  int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                                  unsigned* out_amax, void* stream);
 
+int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, const float* bias, const float* residual,
+                               float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
+                               int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
+                               unsigned* out_amax, void* stream);
+
 int eovae_conv3x3_f16c8_fwd(const float* x, const void* wp, const float* bias, const float* residual, float* y,
                             const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
                             int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                             void* stream) {
-  return eovae_conv3x3_f16c8_fwd_amax(x, wp, bias, residual, y, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, mode, subpix, xpacked,
-                                      gn_sums, gn_groups, nullptr, stream);
+  return eovae_conv3x3_f16c8_fwd_mx(x, nullptr, wp, bias, residual, y, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, mode, subpix,
+                                    xpacked, gn_sums, gn_groups, nullptr, stream);
 }
 
 // As eovae_conv3x3_f16c8_fwd; out_amax (nullable, a pre-zeroed device word) receives the float bits of max|y| by atomicMax
@@ -1855,7 +1914,19 @@ int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bi
                                  const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
                                  int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                                  unsigned* out_amax, void* stream) {
+  return eovae_conv3x3_f16c8_fwd_mx(x, nullptr, wp, bias, residual, y, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, mode, subpix,
+                                    xpacked, gn_sums, gn_groups, out_amax, stream);
+}
+
+// As eovae_conv3x3_f16c8_fwd_amax; x6 (nullable; record input only) = the records' MX-FP6 plane written by
+// eovae_gn_silu_fwd_packed_mx: kernels that have the FP6 form (conv_f16c8_w4.hip) then run the correction product on it at
+// ~1.6 x the fp8 rate; kernels that do not ignore it (the records still carry their e5m2 parts).
+int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, const float* bias, const float* residual,
+                               float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout, int Hout,
+                               int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
+                               unsigned* out_amax, void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_f16c8_fwd: null pointer");
+  EOVAE_CHECK_ARG(!x6 || xpacked, "conv3x3_f16c8_fwd_mx: an FP6 plane belongs to a record input");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_f16c8_fwd: bad shape");
   EOVAE_CHECK_ARG(mode == MODE_NORMAL, "conv3x3_f16c8_fwd: mode %d unsupported (stride-1 'normal' layers and the "
                   "sub-pixel / space-to-depth forms only)", mode);
@@ -1863,7 +1934,7 @@ int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bi
   ConvCArgs a;
   a.x = x; a.wp = (const unsigned char*)wp; a.bias = bias; a.res = residual; a.y = y; a.xamax = xamax;
   a.N = N; a.Hin = Hin; a.Win = Win; a.mode = mode; a.subpix = subpix; a.creal = 0; a.cpb = 1; a.packed = xpacked;
-  a.stagger = 0; a.skew = 0; a.out_amax = out_amax;
+  a.stagger = 0; a.skew = 0; a.out_amax = out_amax; a.x6 = (const unsigned char*)x6; a.mx = 0;
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && !xamax), "conv3x3_f16c8_fwd: packed input is a forward, plain 3x3 input");
   if (subpix == 0) {
     const int eh = mode == MODE_NORMAL ? Hin : 2 * Hin, ew = mode == MODE_NORMAL ? Win : 2 * Win;

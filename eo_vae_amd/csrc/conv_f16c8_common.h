@@ -5,7 +5,7 @@
 
 struct ConvCArgs {
   const float* x;
-  const unsigned char* wp;   // f16c8-packed weights, 16 KiB per (tap, 32-ch chunk, 128-co block) + header
+  const unsigned char* wp;   // f16c8-packed weights, C8_WTILE bytes per (tap, 32-ch chunk, 128-co block) + header
   const float* bias;
   const float* res;
   float* y;
@@ -24,6 +24,9 @@ struct ConvCArgs {
   int skew;                  // conv_f16c8_w4.hip, two blocks per CU: start delay of a CU's second block, units of 4096 cycles
   unsigned* out_amax;        // float bits of max|y| (atomicMax into a pre-zeroed word), or null: the range pre-scale of the
                              // layer that reads y (stride-2 / x2-upsample / data-gradient inputs) without a pass over y
+  const unsigned char* x6;   // packed input only: the records' MX-FP6 plane (groupnorm.hip gn_apply_mx_kernel), or null: the
+                             // correction product then runs on the records' e5m2 parts (fp8 rate)
+  int mx;                    // correction product on block-scaled FP6 operands (below): set by the launcher
 };
 
 // weight-gradient argument block (conv_f16c8.hip wgrad3x3_f16c8_kernel, conv_f16c8_wgrad_w4.hip)
@@ -44,6 +47,18 @@ struct WgCArgs {
   int nseg, units;          // conv_f16c8_wgrad_rows.hip: row segments per strip, units (image x strip x segment) of the walk
 };
 
+// Packed weight tile of one (tap, 32-channel chunk, 128-row block):
+//   [0, 8 KiB)        f16   [octet 0..3][128 m][8 k]
+//   [8 KiB, 16 KiB)   e4m3  [wh' | wl'][half 0..1][128 m][16 k]                  (per-tensor power-of-two scale, header)
+//   [16 KiB, 24 KiB)  MX-FP6 [wh6 | wl6][piece 0..1][128 m][16 B]               (round 5)
+// MX-FP6 operand of one (row, 32-K block): 32 x e2m3 = 6 dwords (v_cvt_scalef32_2xpk16_fp6_f32 of k 0..15 | 16..31) and
+// the block's E8M0 scale byte = max(biased exponent of the block amax - 2, 1) (OCP MX: amax lands in [4, 8), 7.5 saturates),
+// stored as 32 bytes = piece 0 {d0 d1 d2 d3} | piece 1 {d4 d5 scale 0}: a lane's fragment is the two pieces, i.e. the same
+// two ds_read_b128 as the 32 fp8 bytes it replaces; the MFMA reads dwords 0..5 as data and takes dword 6 as its scale
+// operand (byte 0).  The FP6 x FP6 product runs ~1.6 x the fp8 rate (tools/probe_mxfp6.hip), and the per-block scales
+// make it MORE accurate than the per-tensor-scaled fp8 operands.
+constexpr int C8_WTILE = 24576, C8_WOFF8 = 8192, C8_WOFF6 = 16384;
+
 namespace {
 
 enum { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_ZINS = 3 };
@@ -62,6 +77,28 @@ __device__ __forceinline__ float dpp_quad(float x) {
 __device__ __forceinline__ float pow2f(int k) {
   k = k < -126 ? -126 : (k > 127 ? 127 : k);
   return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+}
+// E8M0 scale byte of an MX-FP6 (e2m3) block whose largest magnitude is amax (>= 0, finite)
+__device__ __forceinline__ unsigned mx6_scale_byte(float amax) {
+  const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xff) - 2;
+  return (unsigned)(be < 1 ? 1 : be);
+}
+// 32 values (k = 0..31) -> the two 16-byte pieces of the block's MX-FP6 operand (layout above)
+__device__ __forceinline__ void mx6_quant(const float (&v)[32], float amax, i32x4& p0, i32x4& p1) {
+  typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+  f32x16 a, b;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a[j] = v[j]; b[j] = v[16 + j]; }
+  const unsigned sb = mx6_scale_byte(amax);
+  const float div = __builtin_bit_cast(float, sb << 23);   // the instruction divides by its scale operand
+  // Inline assembly with an EARLY-CLOBBER result: ROCm 7.2's hipcc lets the builtin's 6 result registers overlap its 16-
+  // register sources, and the hardware writes result dwords before it has read every source (tools/probe_cvt_fp6.hip:
+  // wrong fields from the 13th on).  The 32 fields come out interleaved (a[i] -> field 2i, b[i] -> field 2i + 1): every
+  // operand of a product goes through this function, so the k order inside a block is the same on both sides.
+  u32x6 q;
+  asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(q) : "v"(a), "v"(b), "v"(div));
+  p0[0] = (int)q[0]; p0[1] = (int)q[1]; p0[2] = (int)q[2]; p0[3] = (int)q[3];
+  p1[0] = (int)q[4]; p1[1] = (int)q[5]; p1[2] = (int)sb; p1[3] = 0;
 }
 // binary exponent of a positive float given as bits (0 for zero / subnormal input)
 __device__ __forceinline__ int expo_of_bits(unsigned bits) {

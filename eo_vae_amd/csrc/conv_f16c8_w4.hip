@@ -72,8 +72,14 @@ __device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
 // NI = pixel rows per wave: 4 (16-row tiles, one block per CU, 512 registers per wave) or 2 (8-row tiles, TWO blocks
 // per CU with 256 registers per wave, started half a tile apart so that one block's epilogue -- which is bound by the
 // bytes a CU can move, ~13 B/clk, whatever the instruction width -- runs beside the other block's MFMAs).
-template <bool PACKED, int NI>
+// MX (round 5): the correction product on block-scaled FP6 operands (conv_f16c8_common.h) -- phases 9..17 run 16 x
+// v_mfma_scale_f32_32x32x64_f8f6f4 with e2m3 operands (~0.6 x the cycles of the fp8 form), each lane's scale byte riding in
+// dword 6 of its fragment.  Same LDS images, same fragment reads (the 32 FP6 bytes of a lane = 24 data + scale + pad sit
+// where its 32 fp8 bytes sat).  Record input: the FP6 pieces come from the records' MX plane (a.x6:
+// [n][Cin / 32][piece 0..3][pixel][16 B], piece = wave), one 16-byte load and one 16-byte LDS store per task.
+template <bool PACKED, int NI, bool MX>
 __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
+  static_assert(!MX || PACKED, "MX: record input only (the fp32 staging path follows)");
   constexpr int TH = 4 * NI, TW = 32, BM = 128, KC = 32;
   constexpr int XW = TW + 2, NPX = (TH + 2) * XW;          // 18 x 34 = 612 (10 x 34 = 340) halo pixels
   constexpr int IMG = 4 * NPX * 16;                         // one halo image: f16 [4 octets][pixel][8 ch] = 39168 B;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
       xinv = pow2f(e - 13);
     }
   }
-  const unsigned wbits = *reinterpret_cast<const unsigned*>(a.wp + (size_t)9 * a.nchunk * a.ncob * 16384);
+  const unsigned wbits = *reinterpret_cast<const unsigned*>(a.wp + (size_t)9 * a.nchunk * a.ncob * C8_WTILE);
   const int e1 = wbits ? 7 - expo_of_bits(wbits) : 0;
   auto e8m0 = [](int k) { k += 127; return k < 0 ? 0 : (k > 254 ? 254 : k); };
   const int sc_a = e8m0(-e1 - 12);
@@ -158,9 +164,16 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
              (((long)t.n * (a.Cin / 8) + c0 / 8 + wave) * (long)in_plane + origin) * 32;
     return reinterpret_cast<const char*>(a.x) + (((long)t.n * a.Cin + c0 + 8 * wave) * (long)in_plane + origin) * 4;
   };
+  // MX: piece `wave` of the chunk's FP6 plane, 16 bytes per pixel (= half a record's pixel step: offsets xoff / 2)
+  auto x6base = [&](const Tile& t, int c0) __attribute__((always_inline)) {
+    const long origin = (long)(t.oy0 - 1) * a.Win + (t.ox0 - 1);
+    return reinterpret_cast<const char*>(a.x6) +
+           ((((long)t.n * (a.Cin / 32) + c0 / 32) * 4 + wave) * (long)in_plane + origin) * 16;
+  };
   // LDS destinations of task k: compile-time offsets from two lane bases
   const unsigned st16 = (unsigned)(wave * (NPX * 16) + lane * 16);
-  const unsigned st8 = (unsigned)(OFF_X8 + ((wave >> 1) * NPX + lane) * 16 + (wave & 1) * 8);
+  const unsigned st8 = MX ? (unsigned)(OFF_X8 + (wave * NPX + lane) * 16)      // image [part][piece][pixel] = [wave][pixel]
+                          : (unsigned)(OFF_X8 + ((wave >> 1) * NPX + lane) * 16 + (wave & 1) * 8);
 
   // fp32 path: channels 4 q .. 4 q + 3 of task k converted in place: xr[k][4q .. 4q+3] = {f16 pair, f16 pair, lo' x 4, hi' x 4}
   auto convert_half = [&](int k, int q) __attribute__((always_inline)) {
@@ -208,6 +221,15 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     *reinterpret_cast<i32x4*>(smem + dst) = hv;
   };
   auto write8 = [&](int k) __attribute__((always_inline)) {
+    if constexpr (MX) {   // xr[k][4..7] = this wave's 16-byte piece of the pixel's FP6 block
+      const int keep = ((xokm >> k) & 1) ? -1 : 0;
+      i32x4 pv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pv[c] = __builtin_bit_cast(int, xr[k][4 + c]) & keep;
+      const unsigned dst = (k == NTASK - 1 && idle9) ? (unsigned)(OFF_DUMMY + lane * 16) : st8 + k * 1024;
+      *reinterpret_cast<i32x4*>(smem + dst) = pv;
+      return;
+    }
     i32x2 lv, uv;
     if (PACKED) {
       const int keep = ((xokm >> k) & 1) ? -1 : 0;
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   // phase q (0..17) of chunk `chunk` of co-block `cob`: taps' f16 halves first, then their fp8 halves
   auto wsrc = [&](int cob, int chunk, int q) __attribute__((always_inline)) {
     const int tap = q < 9 ? q : q - 9;
-    return a.wp + ((size_t)(tap * a.nchunk + chunk) * a.ncob + cob) * 16384 + (q < 9 ? 0 : 8192) + tid * 16;
+    return a.wp + ((size_t)(tap * a.nchunk + chunk) * a.ncob + cob) * C8_WTILE + (q < 9 ? 0 : (MX ? C8_WOFF6 : C8_WOFF8)) + tid * 16;
   };
   auto w_issue = [&](int set, const unsigned char* src) __attribute__((always_inline)) {
     wreg[set][0] = *reinterpret_cast<const f32x4*>(src);
@@ -296,8 +318,12 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const i32x8 bv = __builtin_shufflevector(Bb[q & 1][j][0], Bb[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0 /* A: e4m3 */, 1 /* B: e5m2 */, 0,
-                                                                    sc_a, 0, sc_b);
+        if constexpr (MX)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 2 /* A: e2m3 */, 2 /* B: e2m3 */, 0,
+                                                                      av[6], 0, bv[6]);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0 /* A: e4m3 */, 1 /* B: e5m2 */, 0,
+                                                                      sc_a, 0, sc_b);
       }
     }
   };
@@ -456,11 +482,13 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     w_issue(0, wsrc(cur.cob, 0, 0));
     w_issue(1, wsrc(cur.cob, 0, 1));
     const char* xb = xbase(cur, 0);
+    const char* x6b = MX ? x6base(cur, 0) : nullptr;
 #pragma unroll
     for (int k = 0; k < NTASK; ++k) {
       if (PACKED) {
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(xb + xoff[k]);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16);
+        const f32x4 q1 = MX ? *reinterpret_cast<const f32x4*>(x6b + (xoff[k] >> 1))
+                            : *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { xr[k][c] = q0[c]; xr[k][4 + c] = q1[c]; }
       } else {
@@ -507,6 +535,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
       const int xchunk = last_chunk ? (has_next_tile ? 0 : chunk) : chunk + 1;
       if (wrap) setup_x(nxt);
       const char* xb = xbase(xt, xchunk * KC);
+      const char* x6b = MX ? x6base(xt, xchunk * KC) : nullptr;
       static_for<0, 18>([&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         constexpr int pn = (p + 1) % 18;
@@ -537,7 +566,8 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
 #pragma unroll
               for (int k = k0; k < k0 + TPP && k < NTASK; ++k) {
                 if (((k - k0) & 3) != i) continue;
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16 * half);
+                const f32x4 qv = (MX && half) ? *reinterpret_cast<const f32x4*>(x6b + (xoff[k] >> 1))
+                                              : *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16 * half);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xr[k][4 * half + c] = qv[c];
               }
@@ -639,11 +669,13 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   a.skew = ni == 2 ? (sk >= 0 ? sk : (a.nchunk * 7 + 2) / 5) : 0;
   const int nblk = ni == 2 ? 2 * n_cu : n_cu;
   const dim3 grid((unsigned)(a.ntiles < nblk ? a.ntiles : nblk)), blk(256);
+  a.mx = (a.packed && a.x6 && ni == 4 && eovae_opt(EOVAE_OPT_C8_MX) != 0) ? 1 : 0;
   if (ni == 2) {
-    if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 2>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 2>), grid, blk, 0, st, a);
+    if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 2, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 2, false>), grid, blk, 0, st, a);
   } else {
-    if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4>), grid, blk, 0, st, a);
+    if (a.mx) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, true>), grid, blk, 0, st, a);
+    else if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4, false>), grid, blk, 0, st, a);
   }
 }

@@ -19,6 +19,7 @@ enum {
   EOVAE_OPT_C8_W4_SKEW,       // experiment (NI = 2): start delay of a CU's second block, units of 4096 cycles; -1 = half a tile
   EOVAE_OPT_C8_WGRAD_W4,      // parked one-wave weight gradient (0)
   EOVAE_OPT_C8_PACK_GATHER,   // per-layer weight packs by the rounds-2/3 per-element gather kernel (0; tests: reference of the LDS-staged pack)
+  EOVAE_OPT_C8_MX,            // correction product on block-scaled FP6 operands where the kernel and its inputs allow it (1); 0: fp8 everywhere
   EOVAE_OPT_COUNT
 };
 int eovae_opt(int id);

@@ -314,6 +314,8 @@ int eovae_gen_gemm(const float* A, const float* B, float* C, const float* bias, 
                    void* stream) {
   EOVAE_CHECK_ARG(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0, "gen_gemm: bad argument");
   EOVAE_CHECK_ARG(epi >= 0 && epi <= 3 && ksplit >= 1, "gen_gemm: epi %d ksplit %d", epi, ksplit);
+  EOVAE_CHECK_ARG(ksplit == 1 || (!bias && epi == 0), "gen_gemm: split-K slices carry no bias / epilogue (ksplit %d, epi %d, "
+                  "bias %s): fold them with eovae_gen_ln_fwd", ksplit, epi, bias ? "given" : "none");
   EOVAE_CHECK_ARG(epi != 1 || aux_out, "gen_gemm: epilogue 1 needs aux_out");
   EOVAE_CHECK_ARG(epi != 2 || aux, "gen_gemm: epilogue 2 needs aux");
   GenGemmArgs g;

@@ -5,6 +5,7 @@
 // statistics are a pure streaming reduction: float4 loads, per-thread fp32 partials, wave64
 // shuffle trees, cross-wave/cross-block combine in double.  Memory-bound (HBM roofline).
 #include "eovae_common.h"
+#include "conv_f16c8_common.h"   // MX-FP6 operand layout (mx6_quant)
 #include <stdlib.h>
 #include <unistd.h>
 #include <chrono>
@@ -184,6 +185,104 @@ __global__ __launch_bounds__(256) void gn_apply_packed_kernel(const float* __res
   i32x4v* rec = reinterpret_cast<i32x4v*>(pa + ((size_t)og * HW + p) * 8);
   rec[0] = a0;
   rec[1] = a1;
+}
+
+// stage 3, f16c8 operand form WITH the MX-FP6 plane (round 5): as gn_apply_packed_kernel, and besides the records
+//   p6[n][C/32][piece 0..3][HW] x 16 B : the block-scaled FP6 (e2m3) operands of the forward convolution's correction
+//   product for channels 32 b .. 32 b + 31 of a pixel -- pieces 0, 1 = (y - f16(y)) ("lo", pairs with the weights' leading
+//   part), pieces 2, 3 = y ("hi", pairs with the weights' residual part); layout of a block: conv_f16c8_common.h.
+// The scale of a block is shared by the 32 channels of ONE pixel (the K axis of the forward convolution), so a thread owns
+// a pixel x 32 channels: 32 coalesced dword loads, 8 + 4 sixteen-byte stores; grid = N * C/32 * ceil(HW / 256).
+// The records keep their e5m2 parts: the weight gradient multiplies along the PIXEL axis and still runs on them.
+template <bool SILU, bool FROM_SUMS>
+__global__ __launch_bounds__(256) void gn_apply_mx_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ stats,
+                                                          const double* __restrict__ sums, double inv_count, float eps,
+                                                          int* __restrict__ pa, int* __restrict__ p6, int C, int HW, int cpg,
+                                                          int pblocks) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const int pb = blockIdx.x % pblocks, bg = blockIdx.x / pblocks;   // bg = n * C/32 + block
+  const int blk = bg % (C / 32), n = bg / (C / 32);
+  const int p = pb * 256 + threadIdx.x;
+  __shared__ float st_s[32][2];   // per channel of the block: scale, shift of y = x * sc + sh
+  if (threadIdx.x < 32) {
+    const int c = blk * 32 + threadIdx.x;
+    const int ng = n * (C / cpg) + c / cpg;
+    float m, r;
+    if constexpr (FROM_SUMS) {
+      const double s_ = sums[(size_t)ng * 2], q_ = sums[(size_t)ng * 2 + 1];
+      const double mean = s_ * inv_count;
+      double var = q_ * inv_count - mean * mean;
+      if (var < 0) var = 0;
+      m = (float)mean;
+      r = (float)(1.0 / sqrt(var + (double)eps));
+      if (pb == 0 && c % cpg == 0) {
+        stats[2 * ng] = m;
+        stats[2 * ng + 1] = r;
+      }
+    } else {
+      m = stats[2 * ng];
+      r = stats[2 * ng + 1];
+    }
+    const float sc = r * gamma[c];
+    st_s[threadIdx.x][0] = sc;
+    st_s[threadIdx.x][1] = beta[c] - m * sc;
+  }
+  __syncthreads();
+  if (p >= HW) return;
+  float v[32], lo[32];
+  const float* xp = x + ((size_t)n * C + blk * 32) * HW + p;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) v[j] = xp[(size_t)j * HW];
+  float ah = 0.f, al = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float o = v[j] * st_s[j][0] + st_s[j][1];
+    v[j] = SILU ? silu_f(o) : o;
+  }
+#pragma unroll
+  for (int oc = 0; oc < 4; ++oc) {
+    int pk[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      int hh;
+      const float v0 = v[8 * oc + j], v1 = v[8 * oc + j + 1];
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v0), "v"(v1));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[8 * oc + j]) : "v"(hh), "v"(v0));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[8 * oc + j + 1]) : "v"(hh), "v"(v1));
+      pk[j >> 1] = hh;
+    }
+    const float* l8 = lo + 8 * oc;
+    const float* v8 = v + 8 * oc;
+    s16x2 l0 = {0, 0}, l1 = {0, 0};
+    l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, l8[0], l8[1], 0x1p-12f, false);
+    l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, l8[2], l8[3], 0x1p-12f, true);
+    l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, l8[4], l8[5], 0x1p-12f, false);
+    l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, l8[6], l8[7], 0x1p-12f, true);
+    int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[0], v8[1], 0, false);
+    h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[2], v8[3], h0, true);
+    int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[4], v8[5], 0, false);
+    h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[6], v8[7], h1, true);
+    i32x4 a0, a1;
+    a0[0] = pk[0]; a0[1] = pk[1]; a0[2] = pk[2]; a0[3] = pk[3];
+    a1[0] = __builtin_bit_cast(int, l0); a1[1] = __builtin_bit_cast(int, l1); a1[2] = h0; a1[3] = h1;
+    i32x4* rec = reinterpret_cast<i32x4*>(pa + (((size_t)n * (C / 8) + blk * 4 + oc) * HW + p) * 8);
+    rec[0] = a0;
+    rec[1] = a1;
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    ah = fmaxf(ah, fabsf(v[j]));
+    al = fmaxf(al, fabsf(lo[j]));
+  }
+  i32x4 q0, q1;
+  i32x4* dst = reinterpret_cast<i32x4*>(p6) + ((size_t)bg * 4) * HW + p;
+  mx6_quant(lo, al, q0, q1);
+  dst[0] = q0;
+  dst[(size_t)HW] = q1;
+  mx6_quant(v, ah, q0, q1);
+  dst[(size_t)2 * HW] = q0;
+  dst[(size_t)3 * HW] = q1;
 }
 
 // backward pass 1: per (n,c) plane  s1 = sum dz, s2 = sum dz * xhat   (dz = dy * silu'(z))
@@ -386,13 +485,26 @@ struct GnBwdFArgs {
 // -- no wave had waited anywhere near two seconds (the runs were not that long); the shader-clock counter is not a
 // trustworthy interval across the chip's clock-state changes.  A reading that jumps backwards or by more than 2^40
 // ticks (three hours) restarts the window instead of ending the wait.
-__device__ __forceinline__ bool gnf_timed_out(unsigned long long& t0) {
+// Round 5: a wave that does time out leaves what it SAW in the launch's 64-byte error block -- diag[1] = the
+// start of its window, [2], [3] = the two elapsed readings (100-MHz ticks), [4] = the shader clock counter, [5] = how often
+// its window was restarted by a jumping reading -- so that the next occurrence is diagnosed from evidence
+// (eovae_gn_bwd_timeout_info, printed by ops.raise_on_gn_backward_timeouts) instead of guessed at.
+__device__ __forceinline__ bool gnf_timed_out(unsigned long long& t0, unsigned long long* diag) {
   const unsigned long long d = __builtin_amdgcn_s_memrealtime() - t0;
   if (d <= 200000000ull) return false;
-  if (d >= (1ull << 40)) { t0 = __builtin_amdgcn_s_memrealtime(); return false; }
+  if (d >= (1ull << 40)) {
+    t0 = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(diag + 5, 1ull);
+    return false;
+  }
   __builtin_amdgcn_s_sleep(8);
   const unsigned long long d2 = __builtin_amdgcn_s_memrealtime() - t0;
-  return d2 > 200000000ull && d2 < (1ull << 40);
+  if (!(d2 > 200000000ull && d2 < (1ull << 40))) return false;
+  diag[1] = t0;
+  diag[2] = d;
+  diag[3] = d2;
+  diag[4] = __builtin_amdgcn_s_memtime();
+  return true;
 }
 
 // The token of THIS launch: the host's per-call value advanced by a device-side epoch that the finalize kernel bumps
@@ -519,7 +631,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_kernel(
           gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
           if (tk == token) break;
-          if (gnf_timed_out(t0)) { late = true; break; }
+          if (gnf_timed_out(t0, a.err)) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         m1 += (double)bits_f(gv[0]);
@@ -678,7 +790,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
           gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
           if (tk == token) break;
-          if (gnf_timed_out(t0)) { late = true; break; }
+          if (gnf_timed_out(t0, a.err)) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         m1 += (double)bits_f(gv[0]);
@@ -767,7 +879,12 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_finalize_kernel(const float2
       const bool bad = *err == token;
       // a time-out also lands in a host-visible word that survives the call (eovae_gn_bwd_timeouts): the NaNs below poison
       // this step's gradients, the host raises at its next check instead of training on
-      if (bad && c == 0) *reinterpret_cast<volatile unsigned long long*>(sticky) = token | 1ull;
+      if (bad && c == 0) {
+        volatile unsigned long long* sv = reinterpret_cast<volatile unsigned long long*>(sticky);
+        for (int i = 1; i < 6; ++i) sv[i] = err[i];     // what the timed-out wave saw (gnf_timed_out)
+        sv[6] = (unsigned long long)N << 48 | (unsigned long long)C << 32 | (unsigned)HW;
+        sv[0] = token | 1ull;
+      }
       dbeta[c] = bad ? __builtin_nanf("") : (float)a1;
       dgamma[c] = bad ? __builtin_nanf("") : (float)a2;
     }
@@ -951,6 +1068,43 @@ int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* be
   return EOVAE_OK;
 }
 
+// As eovae_gn_silu_fwd_packed, and besides the records the MX-FP6 plane of the forward convolution's correction product
+// (gn_apply_mx_kernel): p6 has N*C*HW/2 dwords (2 bytes per element), C must be a multiple of 32.
+int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float* beta, void* pa, void* p6, float* stats,
+                                const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
+                                void* stream) {
+  EOVAE_CHECK_ARG(x && gamma && beta && pa && p6 && stats && ws, "gn_silu_fwd_packed_mx: null pointer");
+  EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C % 32 == 0, "gn_silu_fwd_packed_mx: C=%d G=%d", C, G);
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = C / G;
+  const size_t gsize = (size_t)cpg * HW;
+  const int ns = nsplit_for(gsize);
+  double* part = (double*)ws;
+  const int pblocks = cdiv(HW, 256);
+  const dim3 grid(N * (C / 32) * pblocks);
+  const double inv_count = 1.0 / (double)gsize;
+  if (sums) {
+    if (silu)
+      hipLaunchKernelGGL((gn_apply_mx_kernel<true, true>), grid, dim3(256), 0, st, x, gamma, beta, stats, sums, inv_count, eps,
+                         (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+    else
+      hipLaunchKernelGGL((gn_apply_mx_kernel<false, true>), grid, dim3(256), 0, st, x, gamma, beta, stats, sums, inv_count, eps,
+                         (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+    EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed_mx");
+    return EOVAE_OK;
+  }
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(N * G * ns), dim3(256), 0, st, x, part, gsize, ns);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats, N * G, ns, inv_count, eps);
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_mx_kernel<true, false>), grid, dim3(256), 0, st, x, gamma, beta, stats, (const double*)nullptr,
+                       inv_count, eps, (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+  else
+    hipLaunchKernelGGL((gn_apply_mx_kernel<false, false>), grid, dim3(256), 0, st, x, gamma, beta, stats,
+                       (const double*)nullptr, inv_count, eps, (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+  EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed_mx");
+  return EOVAE_OK;
+}
+
 // switch between the one-pass (fused, default) and the two-pass GroupNorm backward: on = 0 / 1 / 2 sets it (2 = also
 // where the two-pass kernels measured faster), anything else only queries; returns the setting now in force (-1 = not decided yet: EOVAE_GN_BWD_FUSED at first use).
 // eovae_gn_silu_bwd takes the fused kernel when it is on AND the shape allows it (HW a multiple of 1024, team <= 2 x CUs).
@@ -970,6 +1124,20 @@ unsigned long long eovae_gn_bwd_timeouts(int clear) {
   const unsigned long long v = *reinterpret_cast<volatile unsigned long long*>(h);
   if (clear) *reinterpret_cast<volatile unsigned long long*>(h) = 0ull;
   return v;
+}
+
+// What the wave behind the latest time-out saw (gnf_timed_out), for the error message: out[0] = token | 1, [1] = start of
+// its wait window and [2], [3] = its two elapsed readings (100-MHz ticks; the bound is 2e8), [4] = shader clock counter,
+// [5] = window restarts after a jumping reading, [6] = N << 48 | C << 32 | HW of the call, [7] = 0.  Returns 0, or -1
+// when no one-pass backward has run on the current device.
+int eovae_gn_bwd_timeout_info(unsigned long long* out8) {
+  int dev = 0;
+  if (!out8 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEV) return -1;
+  std::lock_guard<std::mutex> lock(g_gn_mu);
+  const unsigned long long* h = g_gn_sticky_host[dev];
+  if (!h) return -1;
+  for (int i = 0; i < 8; ++i) out8[i] = reinterpret_cast<const volatile unsigned long long*>(h)[i];
+  return 0;
 }
 
 // 1 when eovae_gn_silu_bwd would take the fused kernel for this shape
@@ -1046,7 +1214,7 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
           eovae_set_error("gn_silu_bwd: cannot allocate the time-out word");
           return EOVAE_ERR_LAUNCH;
         }
-        *reinterpret_cast<volatile unsigned long long*>(h) = 0ull;
+        for (int i = 0; i < 8; ++i) reinterpret_cast<volatile unsigned long long*>(h)[i] = 0ull;
         g_gn_sticky_host[dev] = reinterpret_cast<unsigned long long*>(h);
         g_gn_sticky_dev[dev] = reinterpret_cast<unsigned long long*>(d);
       }
@@ -1059,6 +1227,23 @@ int eovae_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const
         int e = -1;
         for (int i = 0; i < g_gn_nctl; ++i)
           if (g_gn_ctl[i].dev == dev && g_gn_ctl[i].block == ticket_block) e = i;   // the assignment being recycled
+        if (e >= 0) {
+          // More than GN_MAX_CTL streams have run a one-pass backward on this device: the block's previous stream may
+          // still be drawing tickets from it.  That stream may also be gone, so the device is drained -- once
+          // per recycled block, never in a steady state; inside a stream capture that is not possible: refuse.
+          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            --g_gn_used[dev];
+            eovae_set_error("gn_silu_bwd: the pool of %d ticket blocks is used up and a block cannot be recycled inside a "
+                            "stream capture", GN_MAX_CTL);
+            return EOVAE_ERR_UNSUPPORTED;
+          }
+          if (hipDeviceSynchronize() != hipSuccess) {
+            eovae_set_error("gn_silu_bwd: draining the device before recycling a ticket block failed");
+            return EOVAE_ERR_LAUNCH;
+          }
+        }
         if (e < 0) e = g_gn_nctl < GN_MAX_DEV * GN_MAX_CTL ? g_gn_nctl++ : 0;
         g_gn_ctl[e].dev = dev;
         g_gn_ctl[e].st = st;

@@ -193,6 +193,7 @@ class GpuBatchPrep:
         self.device = device
         self.tables = {m: norm_table(m, norm_scheme) for m in self.modalities} if normalize else {}
         self._dev_tables = {}
+        self._dev_wvs = {}     # one wavelength tensor OBJECT per (modality, device): the generators memoise per tensor object
 
     def _table(self, modality, device):
         key = (modality, str(device))
@@ -229,5 +230,10 @@ class GpuBatchPrep:
             vf = self.rng.random() > 0.5
             k = self.rng.randint(0, 3)
         out = prepare_batch(images, mean, div, clamp, size, hf, vf, k)
-        wvs = torch.tensor(WAVELENGTHS[modality], dtype=torch.float32, device=device)
+        # the same tensor object every batch: dynamic_conv.wavelength_embedding memoises on the object, and a
+        # fresh tensor per batch never hit (11 launches per step stayed, 64 device tensors stayed pinned in the memo)
+        wkey = (modality, str(device))
+        wvs = self._dev_wvs.get(wkey)
+        if wvs is None:
+            wvs = self._dev_wvs[wkey] = torch.tensor(WAVELENGTHS[modality], dtype=torch.float32, device=device)
         return {'image': out, 'wvs': wvs, 'modality': modality}

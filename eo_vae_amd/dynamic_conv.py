@@ -74,7 +74,6 @@ FAST_GENERATOR = os.environ.get('EOVAE_FAST_GENERATOR', '1') != '0'
 # generator_ops: 9 launches per layer forward, ~22 backward, no BLAS library).  EOVAE_GENERATOR_KERNELS=0 keeps the
 # PyTorch-op formulation below for A/B timing and as the fp32 reference of tests/test_gpu_generator.py.
 GENERATOR_KERNELS = os.environ.get('EOVAE_GENERATOR_KERNELS', '1') != '0'
-_TIMING_ONLY_FREEZE = os.environ.get('EOVAE_TIMING_FREEZE_GENERATORS', '0') == '1'
 DEAD_ROW_ELIMINATION = os.environ.get('EOVAE_GENERATOR_DEAD_ROWS', '1') != '0'   # 0: the last layer computes all rows
 
 # The hyper-network's GEMMs are 132-row problems ([132, 256] x [256, 256 .. 2048]).  PyTorch-ROCm's default BLAS
@@ -256,14 +255,6 @@ class _DynamicBase(nn.Module):
         its values, then registered under (1).  A key made of data_ptr/_version alone (round 1) handed
         a recycled address the previous wavelengths' kernels."""
         cacheable = not self.training and not torch.is_grad_enabled()
-        if _TIMING_ONLY_FREEZE:      # EOVAE_TIMING_FREEZE_GENERATORS=1: what the hyper-networks cost a step (timing experiment:
-            hit = self._gen_cache.get('frozen')   # generated kernels without their graph -- NO generator gradients)
-            if hit is None:
-                with torch.no_grad(), sdpa_kernel(SDPBackend.MATH):
-                    waves = get_1d_sincos_pos_embed_from_grid_torch(self.wv_planes, wvs * 1000)
-                    hit = tuple(t.detach() for t in self.weight_generator(self.fclayer(waves)))
-                self._gen_cache['frozen'] = hit
-            return hit
         if cacheable:
             hit = self._gen_cache.get(('id', id(wvs)))
             if hit is not None and hit[0] is wvs and hit[1] == wvs._version:

@@ -75,7 +75,23 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def kernels_apply(x, *params):
+    """Do the HIP kernels of this file take these tensors?  True: x is an fp32 tensor on the GPU (and then every parameter
+    must be fp32 on the same device -- the kernels read raw pointers as fp32; anything else raises instead of being
+    misread).  False: x is not -- a CPU tensor (the generator-only Stage-1 distillation needs no GPU) or another dtype
+    -- and the caller uses the PyTorch-op formulation of the same layer (dynamic_conv._encoder_layer / nn.Linear)."""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return False
+    for t in params:
+        if t is not None and (t.dtype != torch.float32 or t.device != x.device):
+            raise L.EovaeError(f'weight generator: a parameter is {t.dtype} on {t.device}, the input fp32 on {x.device}; the '
+                               'generator kernels read fp32 on one device (keep the hyper-network in fp32: model.float())')
+    return True
+
+
 def linear(x, w, b=None):
+    if not kernels_apply(x, w, b):
+        return torch.nn.functional.linear(x, w, b)
     return LinearFn.apply(x, w, b)
 
 
@@ -197,6 +213,11 @@ class EncoderLayerFn(torch.autograd.Function):
 def encoder_layer(layer, x, keep_from=0):
     """`layer`: an nn.TransformerEncoderLayer in the plain configuration (dynamic_conv._layer_is_plain)."""
     att = layer.self_attn
+    if not kernels_apply(x, att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias, layer.norm1.weight,
+                         layer.norm1.bias, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight,
+                         layer.linear2.bias, layer.norm2.weight, layer.norm2.bias):
+        from .dynamic_conv import _encoder_layer      # the PyTorch-op formulation of the same layer
+        return _encoder_layer(layer, x, keep_from)
     return EncoderLayerFn.apply(x, int(keep_from), att.num_heads, float(layer.norm1.eps), float(layer.norm2.eps),
                                 att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias,
                                 layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,

@@ -37,11 +37,13 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_pack_multi': (_i, [_p, _i, _f, _p]),
     'eovae_conv3x3_f16c8_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     'eovae_conv3x3_f16c8_fwd_amax': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    'eovae_conv3x3_f16c8_fwd_mx': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     'eovae_conv3x3_f16c8_which': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv3x3_f16c8_wgrad_dw_workspace': (_sz, [_i, _i]),
     'eovae_conv3x3_f16c8_wgrad_dw': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     'eovae_gn_silu_fwd_packed': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
+    'eovae_gn_silu_fwd_packed_mx': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     'eovae_subpix_expand': (_i, [_p, _p, _i, _i, _p]),
     'eovae_down_expand': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_down_fold': (_i, [_p, _p, _i, _i, _p]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     'eovae_conv3x3_thin_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_gn_bwd_fused': (_i, [_i]),
     'eovae_gn_bwd_timeouts': (C.c_ulonglong, [_i]),
+    'eovae_gn_bwd_timeout_info': (_i, [C.POINTER(C.c_ulonglong)]),
     'eovae_gn_bwd_fused_eligible': (_i, [_i, _i, _i, _i]),
     'eovae_gemm_f32': (_i, [_p, _p, _p, _i, _i, _i, _i] + [_ll] * 9 + [_f, _p]),
     'eovae_softmax_rows': (_i, [_p, _ll, _i, _p]),
@@ -110,7 +113,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 11  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

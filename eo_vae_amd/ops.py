@@ -233,6 +233,24 @@ def packed_ok(channels):
 PACKED_ACTIVATIONS = os.environ.get('EOVAE_PACKED_ACT', '1') != '0'
 
 
+# Round 5: operand records can carry a second plane -- the MX-FP6 (block-scaled e2m3) operands of the forward convolution's
+# correction product (csrc/groupnorm.hip gn_apply_mx_kernel, 2 bytes per element, alive from the GroupNorm to the convolution
+# that consumes it).  It rides on the records tensor as `_eovae_mx = (plane, version)`; a consumer that does not find it (a
+# clone, a checkpointed re-use) multiplies with the records' e5m2 parts instead -- slower, never wrong.
+def mx_enabled():
+    return CONV_PRECISION == 'f16c8' and L.load().eovae_get_option(b'c8_mx') != 0
+
+
+_LAST_MX = None   # handed from the GroupNorm Function's forward to group_norm_silu(), which tags the tensor autograd returns
+
+
+def mx_plane_of(x):
+    tag = getattr(x, '_eovae_mx', None)
+    if tag is not None and tag[1] == x._version and tag[0].device == x.device and tag[0].numel() * 2 == x.numel():
+        return tag[0]
+    return None
+
+
 # Every 3x3 convolution of the model is followed by a GroupNorm(32) over its output (layers.py:91-92, 106-108;
 # model.py norm_out): the f16c8 forward kernel adds that GroupNorm's (sum, sum of squares) per (image, group) from
 # its epilogue, and the tag below lets group_norm_silu() skip its statistics pass over the tensor.
@@ -322,16 +340,17 @@ def _pack3x3(w4, rows, cols, flip, f16c8):
 
 
 def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None,
-               packed=False, gn_sums=None, out_amax=None):
-    """out_amax (f16c8 only): a zeroed [1] int32 that receives the float bits of max|y| from the kernel's epilogue."""
+               packed=False, gn_sums=None, out_amax=None, x6=None):
+    """out_amax (f16c8 only): a zeroed [1] int32 that receives the float bits of max|y| from the kernel's epilogue.
+    x6 (record input only): the records' MX-FP6 plane (mx_plane_of)."""
     lib = L.load()
     if packed and not f16c8:
         raise L.EovaeError('conv2d: operand-record input reached a non-f16c8 kernel')
     if f16c8:
-        L.check(lib.eovae_conv3x3_f16c8_fwd_amax(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y),
-                                                 L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
-                                                 int(packed), L.ptr(gn_sums), GN_GROUPS_HINT if gn_sums is not None else 0,
-                                                 L.ptr(out_amax), L.stream()), 'eovae_conv3x3_f16c8_fwd')
+        L.check(lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(x), L.ptr(x6) if packed else None, L.ptr(wp), L.ptr(bias), L.ptr(residual),
+                                               L.ptr(y), L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
+                                               int(packed), L.ptr(gn_sums), GN_GROUPS_HINT if gn_sums is not None else 0,
+                                               L.ptr(out_amax), L.stream()), 'eovae_conv3x3_f16c8_fwd')
     else:
         L.check(lib.eovae_conv3x3_bf16_fwd(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), n,
                                            cin_g, h, w, cout_gemm, ho, wo, mode, _PREC[CONV_PRECISION], subpix,
@@ -472,7 +491,7 @@ def pack_pair_f16c8(weight):
     return wp0, wp1
 
 
-def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=False, wp=None):
+def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=False, wp=None, x6=None):
     """3x3 stride-1 conv / data-gradient on the 16-bit matrix cores (weight in PyTorch layout).
     amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode.  wp: an already packed weight."""
     cout, cin = weight.shape[0], weight.shape[1]
@@ -500,7 +519,7 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
     oa = None   # (forward outputs are not tagged: most come from the one-wave-per-SIMD kernel, whose epilogue has no
                 # register for a running maximum, and are read un-normalised by 6 of ~60 layers only)
     _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, None if packed else amax,
-               packed, sums, oa)
+               packed, sums, oa, x6)
     _LAST_GN_SUMS = sums
     _LAST_OUT_AMAX = oa
     if timed:
@@ -776,7 +795,8 @@ class Conv2dFn(torch.autograd.Function):
             # both weight orientations from one amax pass when the data gradient of this layer will be asked for
             if m == MODE_NORMAL and _use_f16c8(cin) and _use_f16c8(cout) and ctx.needs_input_grad[0]:
                 wp, ctx.wp_bwd = pack_pair_f16c8(weight)
-            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed, wp=wp)
+            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed, wp=wp,
+                             x6=mx_plane_of(x) if packed else None)
         elif ks == 1 and CONV_PRECISION != 'f32':
             y = conv1x1_lowp(x, weight, bias_c, res)
         else:
@@ -909,15 +929,33 @@ def conv2d(x, weight, bias=None, residual=None, mode='normal'):
 
 
 def _gn_forward(x, gamma, beta, groups, eps, silu, packed):
+    global _LAST_MX
     n, c, h, w = x.shape
     lib = L.load()
     ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, groups), x.device)
     y = torch.empty_like(x)
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
+    _LAST_MX = None
+    if packed and c % 32 == 0 and mx_enabled():
+        p6 = torch.empty(x.numel() // 2, dtype=torch.float32, device=x.device)
+        L.check(lib.eovae_gn_silu_fwd_packed_mx(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(p6), L.ptr(stats),
+                                                L.ptr(gn_sums_of(x, groups)), n, c, h * w, groups, eps, int(silu), L.ptr(ws),
+                                                L.stream()), 'eovae_gn_silu_fwd_packed_mx')
+        _LAST_MX = p6
+        return y, stats
     fn = lib.eovae_gn_silu_fwd_packed if packed else lib.eovae_gn_silu_fwd
     L.check(fn(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), L.ptr(gn_sums_of(x, groups)), n, c,
                h * w, groups, eps, int(silu), L.ptr(ws), L.stream()), 'eovae_gn_silu_fwd')
     return y, stats
+
+
+def _tag_mx(y):
+    """Attach the MX-FP6 plane the GroupNorm forward just wrote (if any) to the records tensor autograd returned."""
+    global _LAST_MX
+    if _LAST_MX is not None:
+        y._eovae_mx = (_LAST_MX, y._version)
+        _LAST_MX = None
+    return y
 
 
 class GroupNormSiluFn(torch.autograd.Function):
@@ -950,18 +988,48 @@ class GroupNormSiluFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+def gn_timeout_report():
+    """What the timed-out wave saw (csrc/groupnorm.hip gnf_timed_out), as text for the error message."""
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    if L.load().eovae_gn_bwd_timeout_info(buf) != 0:
+        return 'no diagnostics'
+    tok, t0, d1, d2, clk, restarts, shape = (int(buf[i]) for i in range(7))
+    return (f'token {tok:#x}; wait window started at tick {t0}, elapsed readings {d1} and {d2} ticks of 10 ns (bound 2e8), '
+            f'shader clock counter {clk}, window restarts {restarts}; call N={shape >> 48} C={(shape >> 32) & 0xffff} '
+            f'HW={shape & 0xffffffff}')
+
+
+# Data-parallel runs: a time-out is seen by ONE rank; raising there alone leaves the others in the next bucket all-reduce
+# until RCCL's watchdog fires (ADVICE r4).  parallel.BucketedGradReducer reduces a fault flag with every step's gradients
+# and installs this hook: it returns True on EVERY rank in the same step once any rank has reported a time-out.
+GN_TIMEOUT_AGREED = None
+
+
 def raise_on_gn_backward_timeouts():
     """Once per step (training_step): a team of the one-pass GroupNorm backward that timed out has poisoned its
     dgamma / dbeta with NaN; the kernels also leave the event in a host-visible word.  Raises instead of letting the
     optimiser write NaN into every weight.  Sees every launch the host has synchronised with -- at the
-    latest one step after the event."""
-    tok = L.load().eovae_gn_bwd_timeouts(1)
-    if tok and os.environ.get('EOVAE_GN_TIMEOUT_ACTION') == 'warn':      # diagnosis only
-        print(f'[eo_vae_amd] GroupNorm backward time-out recorded (token {tok:#x})', flush=True)
+    latest one step after the event (data parallel: three steps, and on every rank in the same step)."""
+    lib = L.load()
+    if GN_TIMEOUT_AGREED is not None:        # data parallel: the local word stays set until the ranks agree
+        if not GN_TIMEOUT_AGREED():
+            return
+        tok = lib.eovae_gn_bwd_timeouts(0)
+        what = gn_timeout_report() if tok else 'reported by another rank'
+        lib.eovae_gn_bwd_timeouts(1)
+        raise L.EovaeError('GroupNorm backward: a workgroup team timed out waiting for its partial sums on some rank '
+                           f'({what}); the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
+    tok = lib.eovae_gn_bwd_timeouts(0)
+    if not tok:
         return
-    if tok:
-        raise L.EovaeError(f'GroupNorm backward: a workgroup team timed out waiting for its partial sums (token {tok:#x}); '
-                           'the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
+    what = gn_timeout_report()
+    lib.eovae_gn_bwd_timeouts(1)
+    if os.environ.get('EOVAE_GN_TIMEOUT_ACTION') == 'warn':      # diagnosis only
+        print(f'[eo_vae_amd] GroupNorm backward time-out recorded ({what})', flush=True)
+        return
+    raise L.EovaeError(f'GroupNorm backward: a workgroup team timed out waiting for its partial sums ({what}); '
+                       'the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
 
 
 def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
@@ -969,7 +1037,7 @@ def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False
     consumer that is a plain 3x3 Conv2dFn in f16c8 mode."""
     packed = bool(packed and silu and packed_ok(x.shape[1]))
     y = GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu, packed)
-    return mark_packed(y) if packed else y
+    return _tag_mx(mark_packed(y)) if packed else y
 
 
 class GroupNormSiluForkFn(torch.autograd.Function):
@@ -1008,7 +1076,7 @@ class GroupNormSiluForkFn(torch.autograd.Function):
 def group_norm_silu_fork(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
     packed = bool(packed and silu and packed_ok(x.shape[1]))
     y, skip = GroupNormSiluForkFn.apply(x, gamma, beta, groups, eps, silu, packed)
-    return (mark_packed(y) if packed else y), skip
+    return (_tag_mx(mark_packed(y)) if packed else y), skip
 
 
 # ------------------------------------------------------------------------------------------

@@ -71,10 +71,51 @@ class BucketedGradReducer:
         self.works = []
         self.handles = []
         self.main_stream = torch.cuda.current_stream() if flat.grad.is_cuda else None
+        # Fault agreement: a rank-local fault (a GroupNorm-backward time-out: its gradients are NaN) must stop
+        # EVERY rank in the same step -- a rank that raises alone leaves the others in the next all-reduce.  One MAX
+        # all-reduce of a flag rides with every step's buckets; its result is copied to pinned host memory without
+        # blocking and read `HEALTH_LAG` steps later behind that step's event, so every rank examines the same reduced
+        # value of the same step (no host synchronisation with the running step).
+        self.local_fault = self._gn_timeout if flat.grad.is_cuda else (lambda: False)
+        self.health = torch.zeros(1, dtype=torch.float32, device=flat.grad.device)
+        self.health_slots, self.step_no = [], 0
         if self.active:
+            for _ in range(self.HEALTH_LAG + 1):
+                host = torch.zeros(1, dtype=torch.float32)
+                self.health_slots.append([host.pin_memory() if flat.grad.is_cuda else host, None, -1])
+            from . import ops
+            ops.GN_TIMEOUT_AGREED = self.fault_agreed
             for p in flat.params:
                 if p.requires_grad:
                     self.handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    HEALTH_LAG = 2
+
+    @staticmethod
+    def _gn_timeout():
+        from . import lib as L
+        return L.load().eovae_gn_bwd_timeouts(0) != 0
+
+    def _reduce_health(self):
+        self.health.fill_(1.0 if self.local_fault() else 0.0)
+        dist.all_reduce(self.health, op=dist.ReduceOp.MAX, group=self.group)
+        slot = self.health_slots[self.step_no % len(self.health_slots)]
+        slot[0].copy_(self.health, non_blocking=True)
+        slot[1] = torch.cuda.current_stream().record_event() if self.health.is_cuda else None
+        slot[2] = self.step_no
+        self.step_no += 1
+
+    def fault_agreed(self) -> bool:
+        """True on every rank in the same step: some rank reported a fault HEALTH_LAG steps ago."""
+        want = self.step_no - self.HEALTH_LAG
+        if not self.active or want < 0:
+            return False
+        slot = self.health_slots[want % len(self.health_slots)]
+        if slot[2] != want:
+            return False
+        if slot[1] is not None:
+            slot[1].synchronize()
+        return bool(slot[0].item() > 0)
 
     # ---- start-of-training synchronisation (DDP constructor broadcast, C1) ----
     def broadcast_parameters(self, buffers=()):
@@ -115,6 +156,7 @@ class BucketedGradReducer:
                 self._launch(b)
         for w in self.works:
             w.wait()
+        self._reduce_health()
         if not self.use_avg:
             self.flat.grad.mul_(1.0 / self.world)
         if getattr(self.flat, 'detached', False):
@@ -127,3 +169,6 @@ class BucketedGradReducer:
         for h in self.handles:
             h.remove()
         self.handles = []
+        from . import ops
+        if ops.GN_TIMEOUT_AGREED == self.fault_agreed:
+            ops.GN_TIMEOUT_AGREED = None

@@ -110,6 +110,14 @@ int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bi
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups, unsigned* out_amax,
                             void* stream);
+/* as above; x6 (nullable; record input only) = the records' MX-FP6 plane written by eovae_gn_silu_fwd_packed_mx.  Kernels
+ * that have the FP6 form (csrc/conv_f16c8_w4.hip) run the correction product [x_lo | x_hi].[w_hi | w_lo] on block-scaled
+ * e2m3 operands (per-32-channel E8M0 scales, OCP MX) at ~1.6 x the fp8 rate; the others ignore it -- the records keep
+ * their e5m2 parts.  Same call site as eovae_conv3x3_f16c8_fwd (F.conv2d of layers.py:64-66, 81-83). */
+int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, const float* bias, const float* residual,
+                            float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
+                            int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups, unsigned* out_amax,
+                            void* stream);
 /* which kernel the call above launches for these arguments: 1 = conv3x3_f16c8_w4_kernel (csrc/conv_f16c8_w4.hip: one wave
  * per SIMD, 4 x 4 register blocking, 16-row tiles -- plain layers that give every CU two tiles), 0 =
  * conv3x3_f16c8_kernel (8 waves, 8-row tiles: sub-pixel / space-to-depth forms, small grids).  No launch. */
@@ -171,6 +179,13 @@ int eovae_amax_bound_from_sums(const double* sums, int n_groups, unsigned* out_b
 int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
                              const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
                              void* stream);
+/* As eovae_gn_silu_fwd_packed, and besides the records the MX-FP6 plane p6[N][C/32][piece 0..3][HW] x 16 bytes
+ * (N*C*HW/2 dwords; C %% 32 == 0): per pixel and 32 channels the block-scaled e2m3 operands of the forward convolution's
+ * correction product -- pieces 0, 1 = (y - f16(y)), pieces 2, 3 = y; a block = 6 dwords of 32 x 6 bits + its E8M0 scale
+ * byte in dword 6 (csrc/conv_f16c8_common.h).  Hand it to eovae_conv3x3_f16c8_fwd_mx as x6. */
+int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float* beta, void* pa, void* p6, float* stats,
+                                const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
+                                void* stream);
 /* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);
@@ -238,6 +253,10 @@ int eovae_gn_bwd_fused(int on);
  * caller has synchronised with; a trainer checks it once per step (a time-out also poisons that call's dgamma / dbeta
  * with NaN).  clear != 0 resets it. */
 unsigned long long eovae_gn_bwd_timeouts(int clear);
+/* what the wave behind the latest time-out saw: out8[0] = token | 1, [1] = start of its wait window and [2], [3] = its two
+ * elapsed readings (100-MHz ticks; the bound is 2e8), [4] = shader clock counter, [5] = window restarts after a jumping
+ * reading, [6] = N << 48 | C << 32 | HW of the call, [7] = 0.  0, or -1 when no one-pass backward has run on the device. */
+int eovae_gn_bwd_timeout_info(unsigned long long* out8);
 int eovae_gn_bwd_fused_eligible(int N, int C, int HW, int G);
 /* dx = d/dx (+ dx_add if not NULL); dgamma[C], dbeta[C]; dx_amax_bits (nullable, device): receives the
  * float bits of max|dx| -- the pre-scale input of eovae_conv3x3_f16c8_fwd's data-gradient calls, produced

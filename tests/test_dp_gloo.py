@@ -168,3 +168,51 @@ def test_running_stats_merge_across_ranks_world2():
         assert torch.allclose(st[1], pooled.var(1, unbiased=False), rtol=1e-4, atol=1e-6)
         assert torch.equal(st[2], pooled.amin(1)) and torch.equal(st[3], pooled.amax(1))
         assert torch.all(st[4] == pooled.shape[1])
+
+
+def _fault_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from eo_vae_amd import ops
+    from eo_vae_amd.optim import FlatParams
+    from eo_vae_amd.parallel import BucketedGradReducer, init_distributed
+    init_distributed('gloo')
+    model = _make_model()
+    flat = FlatParams(model.parameters())
+    red = BucketedGradReducer(flat, bucket_mb=0.002)
+    assert ops.GN_TIMEOUT_AGREED == red.fault_agreed
+    state = {'step': -1}
+    red.local_fault = lambda: rank == 1 and state['step'] == 1      # ONE rank sees a fault, in its step 1
+    g = torch.Generator().manual_seed(7 + rank)
+    seen = []
+    for step in range(6):
+        state['step'] = step
+        seen.append(red.fault_agreed())          # what training_step asks before it enqueues anything
+        flat.zero_grad()
+        torch.nn.functional.mse_loss(model(torch.randn(4, 10, generator=g)), torch.randn(4, 3, generator=g)).backward()
+        red.finish()
+    red.remove()
+    assert ops.GN_TIMEOUT_AGREED is None
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_local_fault_stops_every_rank_in_the_same_step():
+    """a GroupNorm-backward time-out is seen by one rank; the flag rides a MAX all-reduce beside the gradient
+    buckets and every rank reads the same reduced value HEALTH_LAG steps later -- both ranks agree, in the same step."""
+    from eo_vae_amd.parallel import BucketedGradReducer
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    lag = BucketedGradReducer.HEALTH_LAG
+    want = [s == 1 + lag for s in range(6)]
+    assert res[0] == want and res[1] == want

@@ -23,8 +23,11 @@ def f16c8_mode(request):
     from eo_vae_amd import lib as L, ops
     lib = L.load()
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
-    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_w4_ni')}
+    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_w4_ni', b'c8_mx')}
     L.check(lib.eovae_set_option(b'c8_w4_ni', int(request.param)), 'set_option')
+    # the comparisons below are "same products, other summation order": both kernels on the fp8 form of the correction
+    # product (the one-wave kernel's MX-FP6 form has its own tests, tests/test_gpu_mx.py)
+    L.check(lib.eovae_set_option(b'c8_mx', 0), 'set_option')
     yield
     ops.CONV_PRECISION = old
     for k, v in keep.items():

@@ -1,0 +1,168 @@
+"""GPU: the MX-FP6 form of the f16c8 correction product (round 5; csrc/conv_f16c8_common.h).
+
+The operands are checked at three levels: (1) the bytes -- the GroupNorm records' FP6 plane and the weight packs' FP6 part
+decode to exactly what oracle/mx_emul.py says they hold; (2) the product -- a convolution on those operands equals the
+float64 sum of the SAME three products (f16 x f16 + the two corrections on the block-scaled e2m3 images) to summation-order
+accuracy; (3) the scheme -- it stays within the f16c8 error of plain fp32, and the fp8 form (library option c8_mx = 0) is
+still there behind the same call."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.fixture(autouse=True)
+def f16c8_mx():
+    from eo_vae_amd import lib as L, ops
+    lib = L.load()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_mx')}
+    L.check(lib.eovae_set_option(b'c8_mx', 1), 'set_option')
+    yield
+    ops.CONV_PRECISION = old
+    for k, v in keep.items():
+        lib.eovae_set_option(k, v)
+
+
+def set_opt(name, v):
+    from eo_vae_amd import lib as L
+    L.check(L.load().eovae_set_option(name, v), 'set_option')
+
+
+def plane_values(p6, n, c, hw):
+    """MX plane [n][c/32][piece 0..3][hw][4 dwords] -> (lo, hi) float64 [n, c, hw]."""
+    from oracle import mx_emul as M
+    a = p6.view(torch.int32).cpu().numpy().reshape(n, c // 32, 4, hw, 4)
+    out = []
+    for part in range(2):
+        pieces = np.concatenate([a[:, :, 2 * part], a[:, :, 2 * part + 1]], axis=-1)      # [n, c/32, hw, 8]
+        v = M.decode_blocks(pieces)                                                       # [n, c/32, hw, 32]
+        out.append(torch.from_numpy(v).permute(0, 1, 3, 2).reshape(n, c, hw))
+    return out
+
+
+@pytest.mark.parametrize('n,c,h,w,spread', [(2, 64, 16, 32, 0), (1, 128, 8, 40, 12)])
+def test_records_plane_holds_the_emulated_operands(n, c, h, w, spread):
+    """spread: per-pixel magnitudes over 2^-spread .. 1 -- the block scales follow each pixel."""
+    from eo_vae_amd import ops
+    from oracle import mx_emul as M
+    torch.manual_seed(c + h)
+    x = torch.randn(n, c, h, w, device='cuda') * 2 + 0.3
+    gamma = torch.randn(c, device='cuda')
+    if spread:
+        gamma = gamma * torch.exp2(-torch.randint(0, spread, (c,), device='cuda').float())
+    beta = torch.randn(c, device='cuda') * 0.1
+    with torch.no_grad():
+        a = ops.group_norm_silu(x, gamma, beta, packed=True)
+        z = ops.group_norm_silu(x, gamma, beta, packed=False).cpu()
+    p6 = ops.mx_plane_of(a)
+    assert ops.is_packed(a) and p6 is not None and p6.numel() * 2 == x.numel()
+    lo, hi = plane_values(p6, n, c, h * w)
+    zl = z - M.f16(z)
+    for got, src in ((hi, z), (lo, zl)):
+        want = M.mx6_quant(src, 1).reshape(n, c, h * w)
+        # the two GroupNorm kernels may round exp() apart by an ulp: a handful of elements may sit one code apart
+        bad = (got != want)
+        assert bad.float().mean().item() < 2e-3
+        blockmax = src.abs().reshape(n, c // 32, 32, h * w).amax(2, keepdim=True).expand(-1, -1, 32, -1).reshape(n, c, h * w)
+        assert ((got - want).abs() <= 0.1251 * blockmax.double() + 1e-300).all()    # never more than one code step of the block
+
+
+@pytest.mark.parametrize('cout,cin', [(128, 64), (160, 96)])
+def test_weight_pack_holds_the_emulated_operands(cout, cin):
+    from eo_vae_amd import lib as L
+    from oracle import mx_emul as M
+    lib = L.load()
+    torch.manual_seed(cout)
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5) * torch.exp2(torch.randint(-6, 2, (cout, 1, 1, 1)).float())
+    wd = w.cuda()
+    for flip in (0, 1):
+        rows, ks = (cin, cout) if flip else (cout, cin)
+        nchunk, ncob = (ks + 31) // 32, (rows + 127) // 128
+        wp = torch.zeros(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, flip), dtype=torch.uint8, device='cuda')
+        L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(wd), L.ptr(wp), cout, cin, flip, 1.0, L.stream()), 'pack')
+        tiles = wp[:9 * nchunk * ncob * 24576].cpu().numpy().reshape(9, nchunk, ncob, 24576)
+        fp6 = tiles[..., 16384:].copy().view(np.int32).reshape(9, nchunk, ncob, 2, 2, 128, 4)   # [part][piece][m][4]
+        # K axis: ci (forward) / co (data gradient, taps reversed); rows m: co / ci
+        wk = w if not flip else w.flip(2, 3).transpose(0, 1)       # [m][k][3][3]
+        wl = wk - M.f16(wk)
+        for part, src in ((0, wk), (1, wl)):
+            want = M.mx6_quant(src, 1)                              # blocks of 32 k per (m, tap)
+            pieces = np.concatenate([fp6[:, :, :, part, 0], fp6[:, :, :, part, 1]], axis=-1)    # [9, nchunk, ncob, 128, 8]
+            got = M.decode_blocks(pieces)                                                       # [9, nchunk, ncob, 128, 32]
+            got = torch.from_numpy(got).permute(2, 3, 1, 4, 0).reshape(ncob * 128, nchunk * 32, 9)[:rows, :ks]
+            assert torch.equal(got, want.reshape(rows, ks, 9)), (flip, part)
+            # padding rows / channels are zero blocks
+            pad = torch.from_numpy(M.decode_blocks(pieces)).permute(2, 3, 1, 4, 0).reshape(ncob * 128, nchunk * 32, 9)[rows:]
+            assert pad.numel() == 0 or pad.abs().max() == 0
+
+
+@pytest.mark.parametrize('n,c,cout,h,w', [(2, 64, 128, 32, 64), (5, 128, 256, 64, 128), (1, 192, 128, 16, 32)])
+def test_forward_on_records_equals_the_emulated_product(n, c, cout, h, w):
+    from eo_vae_amd import ops
+    from oracle import mx_emul as M
+    torch.manual_seed(c + h)
+    x = torch.randn(n, c, h, w, device='cuda') * 2 + 0.3
+    gamma, beta = torch.randn(c, device='cuda'), torch.randn(c, device='cuda')
+    wt = torch.randn(cout, c, 3, 3, device='cuda') / (c * 9) ** 0.5
+    b = torch.randn(cout, device='cuda')
+    res = torch.randn(n, cout, h, w, device='cuda')
+    set_opt(b'c8_w4', 1)
+
+    def fwd(mx):
+        set_opt(b'c8_mx', mx)
+        with torch.no_grad():
+            a = ops.group_norm_silu(x, gamma, beta, packed=True)
+            assert (ops.mx_plane_of(a) is not None) == bool(mx)
+            y = ops.conv2d(a, wt, b, res, 'normal')
+        torch.cuda.synchronize()
+        return y
+    y_mx, y_f8 = fwd(1), fwd(0)
+    with torch.no_grad():
+        z = ops.group_norm_silu(x, gamma, beta, packed=False).cpu()
+    conv = lambda a_, b_: F.conv2d(a_, b_, padding=1)
+    want = M.split_product(z, wt.cpu(), conv) + b.cpu().double().view(1, -1, 1, 1) + res.cpu().double()
+    exact = conv(z.double(), wt.cpu().double()) + b.cpu().double().view(1, -1, 1, 1) + res.cpu().double()
+    assert rel(y_mx, want) < 3e-6          # the same three products: fp32 summation order (+ rare one-code differences of z)
+    assert rel(y_mx, exact) < 5e-5         # the scheme against fp64
+    assert rel(y_f8, exact) < 5e-5 and rel(y_mx, y_f8) < 5e-5
+    assert rel(y_mx, y_f8) > 1e-8          # and the two forms really are different arithmetic
+
+
+def test_resnet_block_with_and_without_mx():
+    """Forward + backward of a ResnetBlock: the FP6 plane changes the forward products only; gradients stay within the scheme's
+    error of each other, and a records tensor that lost its plane (clone) still multiplies correctly."""
+    from eo_vae_amd import ops
+    from eo_vae_amd.layers import ResnetBlock
+    torch.manual_seed(3)
+    blk = ResnetBlock(128, 128).cuda()
+    x = torch.randn(4, 128, 64, 64, device='cuda')
+    gy = torch.randn(4, 128, 64, 64, device='cuda') * 1e-3
+
+    def step(mx):
+        set_opt(b'c8_mx', mx)
+        for p in blk.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y = blk(xg)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return [y.detach(), xg.grad.detach()] + [p.grad.detach().clone() for p in blk.parameters()]
+    a, b = step(1), step(0)
+    for u, v in zip(a, b):
+        assert rel(u, v) < 2e-4
+    set_opt(b'c8_mx', 1)
+    with torch.no_grad():
+        rec = ops.group_norm_silu(x, blk.norm1.weight, blk.norm1.bias, packed=True)
+        y1 = ops.conv2d(rec, blk.conv1.weight, blk.conv1.bias, None, 'normal')
+        y2 = ops.conv2d(rec.clone(), blk.conv1.weight, blk.conv1.bias, None, 'normal')    # no plane: fp8 parts of the records
+    assert ops.mx_plane_of(rec) is not None and ops.mx_plane_of(rec.clone()) is None
+    assert rel(y1, y2) < 5e-5

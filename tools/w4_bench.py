@@ -31,18 +31,26 @@ for cin, cout, hw in shapes:
     flops = 2.0 * B * hw * hw * cin * cout * 9
     wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
     L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
-    xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True).detach()
+    with torch.no_grad():
+        xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True)
+    x6 = ops.mx_plane_of(xrec)     # round 5: the records' MX-FP6 plane (None when the library option c8_mx is 0)
+    # variant '2' = the w4 kernel with the correction product on MX-FP6 operands (record input only)
     cases = {
-        'fwd rec+gn+res': lambda: lib.eovae_conv3x3_f16c8_fwd(L.ptr(xrec), L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, L.stream()),
-        'fwd rec+gn    ': lambda: lib.eovae_conv3x3_f16c8_fwd(L.ptr(xrec), L.ptr(wp), L.ptr(bias), None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, L.stream()),
-        'dgrad fp32+amax': lambda: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()),
+        'fwd rec+gn+res': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xrec), L.ptr(x6) if v == '2' else None, L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, None, L.stream()),
+        'fwd rec+gn    ': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xrec), L.ptr(x6) if v == '2' else None, L.ptr(wp), L.ptr(bias), None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, None, L.stream()),
+        'dgrad fp32+amax': lambda v: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()),
     }
-    best = {(k, v): 1e9 for k in cases for v in '01'}
+    variants = '012' if x6 is not None else '01'
+    best = {(k, v): 1e9 for k in cases for v in variants}
     for rnd in range(3):
         for k, f in cases.items():
-            for v in '01':
-                lib.eovae_set_option(b'c8_w4', int(v))
-                best[(k, v)] = min(best[(k, v)], timeit(f))
+            for v in variants:
+                if v == '2' and k.startswith('dgrad'):
+                    continue
+                lib.eovae_set_option(b'c8_w4', 0 if v == '0' else 1)
+                best[(k, v)] = min(best[(k, v)], timeit(lambda: f(v)))
     for k in cases:
         t0, t1 = best[(k, '0')], best[(k, '1')]
-        print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 {k}: 8-wave {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | w4 {t1:7.3f} ms {flops/t1/1e9:6.1f} TF | x{t0/t1:.3f}', flush=True)
+        t2 = best.get((k, '2'), 1e9)
+        mx = f' | w4 mx-fp6 {t2:7.3f} ms {flops/t2/1e9:6.1f} TF x{t1/t2:.3f} of w4' if t2 < 1e8 else ''
+        print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 {k}: 8-wave {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | w4 {t1:7.3f} ms {flops/t1/1e9:6.1f} TF | x{t0/t1:.3f}{mx}', flush=True)
