@@ -29,6 +29,7 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
     {"c8_wgrad_w4", "EOVAE_C8_WGRAD_W4", 0},       // conv_f16c8_wgrad_w4.hip (parked: slower than the 8-wave kernels)
     {"c8_pack_gather", "EOVAE_C8_PACK_GATHER", 0}, // per-layer weight packs by the per-element gather kernel (reference of the LDS-staged one)
     {"c8_mx", "EOVAE_C8_MX", 1},                   // MX-FP6 correction product (conv_f16c8_common.h); 0 = the fp8 form everywhere
+    {"c8_wgrad_corr", "EOVAE_C8_WGRAD_CORR", 0},   // 1: the row-streaming weight gradients keep their fp8 correction product (r4); 0: f16 x f16 alone
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};

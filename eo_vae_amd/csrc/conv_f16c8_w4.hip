@@ -314,10 +314,20 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ab[i & 1][s]),
                                                             __builtin_bit_cast(f16x8, Bb[q & 1][j][s]), acc[i][j], 0, 0, 0);
     } else {
-      const i32x8 av = __builtin_shufflevector(Ab[i & 1][0], Ab[i & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      i32x8 av = __builtin_shufflevector(Ab[i & 1][0], Ab[i & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      // MX: the MFMA reads dwords 0..5 of a fragment as data and dword 6 as its scale.  Left alone, hipcc gives it a
+      // SIX-register operand and copies dwords 4, 5 of the second ds_read_b128 next to the first one (two v_mov and an
+      // early lgkmcnt wait per fragment: 16 per phase).  The empty asm keeps the fragment one eight-register tuple, of which
+      // the operand and the scale are sub-registers.
+      if constexpr (MX) asm("" : "+v"(av));
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const i32x8 bv = __builtin_shufflevector(Bb[q & 1][j][0], Bb[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        i32x8 bv = __builtin_shufflevector(Bb[q & 1][j][0], Bb[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (MX && i == 0) {   // once per fragment, written back: the later co-tiles read the same tuple
+          asm("" : "+v"(bv));
+          Bb[q & 1][j][0] = __builtin_shufflevector(bv, bv, 0, 1, 2, 3);
+          Bb[q & 1][j][1] = __builtin_shufflevector(bv, bv, 4, 5, 6, 7);
+        }
         if constexpr (MX)
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 2 /* A: e2m3 */, 2 /* B: e2m3 */, 0,
                                                                       av[6], 0, bv[6]);

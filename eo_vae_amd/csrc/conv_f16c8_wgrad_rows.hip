@@ -141,7 +141,15 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
 // actual MFMA work).  Two dY slots of two planes (a row's fragments are read once, at the start of the stage after its
 // conversion) keep the LDS at 157 KiB.  The fold (wgrad_up_fold_kernel) sums the splits and maps (parity, a, b) back to
 // the nine taps of the layer's kernel.
-template <int SP>
+// CORR (round 5): false = the weight gradient's product is f16(dY) * f16(X) ALONE -- no fp8 correction product: the nine (SP:
+// eight) scaled MFMAs of a stage, the dY residual / e5m2 conversions and stores, the second LDS-DMA of every X row, the
+// fp8 fragment reads and the A8 register ring all go; a stage is 18 (16) f16 MFMAs = half the matrix-pipe cycles.  Why that
+// is sound here and nowhere else: a weight gradient is a LEAF -- its rounding errors (two f16 roundings per term, random
+// over >= 10^4 pixels) do not feed another product, whereas the forward and data-gradient errors compound through ~60
+// layers; tools/scheme_probe_grad.py / profiles/r05_scheme_probe_wgrad.log (emulation) and the full-size pins of
+// tests/test_gpu_model.py hold the same gradient bars as before.  true = the r4 arithmetic (library option
+// c8_wgrad_corr = 1).
+template <int SP, bool CORR>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char dys[SP ? 4 * DYSLOT : NRING * DYSLOT];   // SP: 2 slots x 2 pixel planes
   // FOUR arrays for the LDS-DMA targets (X row s + 3 is requested in stage s; row s + 1 is already read at the end of
@@ -295,6 +303,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
       dbs += t0 + t1;
     }
     i32x2 hi;
+    if constexpr (!CORR) {   // leading parts only
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        int hp;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[j]), "v"(v[j + 1]));
+        hi[j >> 1] = hp;
+      }
+      *reinterpret_cast<i32x2*>(slot + dw16 + 8 * I) = hi;
+      (void)lo;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
       int hp;
@@ -323,8 +342,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xbase), 0, ok ? xspan : 0u, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x16dst), 16, (int)vx, so, 0, 0);
     // (the records' second halves through the SCALAR offset: an LDS-DMA's immediate offset also moves its LDS address)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x8dst), 16, (int)vx, so + 16, 0, 0);
+    if constexpr (CORR)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(xslot + x8dst), 16, (int)vx, so + 16, 0, 0);
   };
+  // vector-memory operations of one stage's requests: dY row (2, SP: 4 loads) + X row (CORR: 2 DMAs, else 1)
+  constexpr int NDY = SP ? 4 : 2, NX = CORR ? 2 : 1;
 
   // ---- fragment addresses (per-lane constants; slot, tap shift and k-step are immediates)
   // A (dY): lane (r, h) reads row 32 ct + r; f16: 8 pixels at 16 h of the k-step; fp8: the row's 32 bytes of image h
@@ -386,7 +408,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   __syncthreads();
   // the fp8 B fragment of a stage's first MFMAs is read at the end of the stage before it (X rows land two stages
   // ahead): behind the barrier a stage starts multiplying at once, on operands that are all in registers
-  i32x8 b8 = rtr8(xs0 + b8off);
+  i32x8 b8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 nb0 = A16[0][0], nb1 = A16[0][0];   // !CORR: the B fragments of the next sub-step, read one sub-step ahead
+  if constexpr (CORR) {
+    b8 = rtr8(xs0 + b8off);
+  } else {
+    nb0 = rtr16(xs0 + b16off, xs0 + b16off + 4 * 16);
+    nb1 = rtr16(xs0 + b16off + 16 * 16, xs0 + b16off + 20 * 16);
+  }
 
   // stage s: S = s mod 12; K = s mod 3 (dY slots, register ring), P = s mod 2 (dY register set that receives row s + 2; row
   // s + 1 sits in the other), Q = s mod 4 (X slot)
@@ -405,13 +434,57 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     // fragments are requested first thing and are needed by the third MFMA.  The requests of dY row s + 2 and X row
     // s + 3 and the cursor step ride between the MFMAs of kx = 0, the conversion of dY row s + 1 (requested a stage ago)
     // between the triples of kx = 1.
-    {
+    if constexpr (CORR) {
       const i32x4 l = *reinterpret_cast<const i32x4*>(dsl + a8off), u = *reinterpret_cast<const i32x4*>(dsl + a8off + 16);
       A8[K] = (i32x8)__builtin_shufflevector(l, u, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off));
     A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off + 32));
     constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3;   // ring positions of ky = 1, 2 (ky = 0: K)
+    if constexpr (!CORR) {
+      // 18 f16 MFMAs.  Per kx: the two OLD rows (register ring) first -- four MFMAs on operands that are in registers when
+      // the barrier opens (their B fragments were read one sub-step ahead) -- then the new row, whose A fragments were
+      // requested above.  Requests ride between the MFMAs of kx = KREQ, the conversion of dY row s + 1 at kx = KCNV.
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f16x8 b0 = nb0, b1 = nb1;
+        if (kx == KCNV) {
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + NDY + NX) : "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3)
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(acc[3 + kx], A16[R1][0], b0);
+        if (kx == KREQ) {
+          __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
+          if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
+        }
+        mfma16(acc[6 + kx], A16[R2][0], b0);
+        if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) {
+          request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
+          save_dy();
+        }
+        mfma16(acc[3 + kx], A16[R1][1], b1);
+        if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) step();
+        mfma16(acc[6 + kx], A16[R2][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kx < 2) {
+          nb0 = rtr16(xsl + b16off + (kx + 1) * 16, xsl + b16off + (kx + 5) * 16);
+          nb1 = rtr16(xsl + b16off + (kx + 17) * 16, xsl + b16off + (kx + 21) * 16);
+        } else {   // the next stage's first B fragments
+          const unsigned char* xn = xslot_of(std::integral_constant<int, (Q + 1) % 4>{});
+          nb0 = rtr16(xn + b16off, xn + b16off + 4 * 16);
+          nb1 = rtr16(xn + b16off + 16 * 16, xn + b16off + 20 * 16);
+        }
+        if (kx == KCNV && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(acc[kx], A16[K][0], b0);
+        mfma16(acc[kx], A16[K][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + NX) : "memory");   // X(s + 2) has landed: only this stage's requests may be outstanding
+      if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      return;
+    }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const f16x8 b0 = rtr16(xsl + b16off + kx * 16, xsl + b16off + (kx + 4) * 16);
@@ -464,12 +537,66 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     const unsigned char* dsl = dys + K * (2 * DYSLOT);
     unsigned char* dnx = dys + R1 * (2 * DYSLOT);
     const unsigned char* xsl = xslot_of(std::integral_constant<int, Q>{});
-    {
+    if constexpr (CORR) {
       const i32x4 l = *reinterpret_cast<const i32x4*>(dsl + a8off), u = *reinterpret_cast<const i32x4*>(dsl + a8off + 16);
       A8[K] = (i32x8)__builtin_shufflevector(l, u, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off));
     A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off + 32));
+    if constexpr (!CORR) {
+      // 16 f16 MFMAs: per sub-step (kx, ci-tile) the old row's two k-steps first (operands in registers), then the new row's
+      static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+        constexpr int IT = decltype(itc)::value, kx = IT >> 1, ci = IT & 1;
+        f32x16& accK = acc[4 * ci + kx];        // a = 0: the new row
+        f32x16& accR = acc[4 * ci + 2 + kx];    // a = 1: the row before it
+        const f16x8 b0 = nb0, b1 = nb1;
+        if constexpr (IT == 1) {
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + NDY + NX) : "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3)
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
+        }
+        if constexpr (IT == 2) {
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C2{}, dnx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool useR = !(SP == 2 && py == 1), useB = !(SP == 2 && kx == 1 && pxw == 1);
+        if (useR && useB) mfma16(accR, A16[R1][0], b0);
+        if constexpr (IT == 0) {
+          __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
+          if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
+        }
+        if (useR && useB) mfma16(accR, A16[R1][1], b1);
+        if constexpr (IT == 0) {
+          if (!(EOVAE_ROWS_ABL & 2)) {
+            request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
+            save_dy();
+            step();
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (IT < 3) {
+          constexpr int nkx = (IT + 1) >> 1, nci = (IT + 1) & 1, NO = nci * 4 * XP16;
+          nb0 = rtr16(xsl + b16off + NO + nkx * 16, xsl + b16off + NO + (nkx + 4) * 16);
+          nb1 = rtr16(xsl + b16off + NO + (nkx + 16) * 16, xsl + b16off + NO + (nkx + 20) * 16);
+        } else {   // the next stage's first B fragments
+          const unsigned char* xn = xslot_of(std::integral_constant<int, (Q + 1) % 4>{});
+          nb0 = rtr16(xn + b16off, xn + b16off + 4 * 16);
+          nb1 = rtr16(xn + b16off + 16 * 16, xn + b16off + 20 * 16);
+        }
+        if constexpr (IT == 1) {
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
+        }
+        if constexpr (IT == 2) {
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C3{}, dnx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (useB) mfma16(accK, A16[K][0], b0);
+        if (useB) mfma16(accK, A16[K][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + NX) : "memory");   // X(s + 2) has landed
+      if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      return;
+    }
     static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
       constexpr int IT = decltype(itc)::value, kx = IT >> 1, ci = IT & 1;
       constexpr int XO16 = ci * 4 * XP16, XO8 = ci * X8T;
@@ -700,7 +827,10 @@ void eovae_c8_wgrad_rows_launch(WgCArgs& a, hipStream_t st) {
   a.units = strips * nseg;
   if (a.split > a.units) a.split = a.units;
   a.xcd_remap = (a.ncib * a.ncob_ > 1 && a.split % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<0>, dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
+  if (eovae_opt(EOVAE_OPT_C8_WGRAD_CORR))
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<0, true>), dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<0, false>), dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
 }
 
 // ---- the x2-upsample layer ("nearest x2 + 3x3", layers.py Upsample) in sub-pixel row-streaming form
@@ -754,7 +884,10 @@ int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, flo
   if (a.split > a.units) a.split = a.units;
   const int nslab = 2 * a.ncib * a.ncob_;
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<1>, dim3(nslab * a.split), dim3(512), 0, st, a);
+  if (eovae_opt(EOVAE_OPT_C8_WGRAD_CORR))
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<1, true>), dim3(nslab * a.split), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<1, false>), dim3(nslab * a.split), dim3(512), 0, st, a);
   hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)(a.ncib * a.ncob_ * 128)), dim3(576), 0, st, a.part, dw, Cout, Cin, a.ncib,
                      a.split);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_up");
@@ -797,7 +930,10 @@ int eovae_conv3x3_f16c8_wgrad_down(const float* x, const float* dy, float* dw, c
   if (a.split > a.units) a.split = a.units;
   const int nslab = 2 * a.ncib * a.ncob_;
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(wgrad3x3_f16c8_rows_kernel<2>, dim3(nslab * a.split), dim3(512), 0, st, a);
+  if (eovae_opt(EOVAE_OPT_C8_WGRAD_CORR))
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<2, true>), dim3(nslab * a.split), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<2, false>), dim3(nslab * a.split), dim3(512), 0, st, a);
   hipLaunchKernelGGL(wgrad_down_fold_kernel, dim3((unsigned)(a.ncib * a.ncob_ * 32)), dim3(576), 0, st, a.part, dw, Cout, Cin, a.ncib,
                      a.split);
   EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad_down");

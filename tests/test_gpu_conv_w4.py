@@ -23,11 +23,14 @@ def f16c8_mode(request):
     from eo_vae_amd import lib as L, ops
     lib = L.load()
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
-    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_w4_ni', b'c8_mx')}
+    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_w4_ni', b'c8_mx', b'c8_wgrad_corr')}
     L.check(lib.eovae_set_option(b'c8_w4_ni', int(request.param)), 'set_option')
     # the comparisons below are "same products, other summation order": both kernels on the fp8 form of the correction
     # product (the one-wave kernel's MX-FP6 form has its own tests, tests/test_gpu_mx.py)
     L.check(lib.eovae_set_option(b'c8_mx', 0), 'set_option')
+    # ... and the weight gradient with its correction product: the plain-f16 form rounds the activations to f16, and an
+    # activation that differs in its last fp32 bit between the two forward kernels can round the other way (2^-11 apart)
+    L.check(lib.eovae_set_option(b'c8_wgrad_corr', 1), 'set_option')
     yield
     ops.CONV_PRECISION = old
     for k, v in keep.items():

@@ -190,7 +190,13 @@ def _lowp_case(n, cin, cout, h, w, ks, mode, precision, tol, gscale=1.0, xscale=
         ops.CONV_PRECISION = old
     assert rel_err(yg, yr) < tol
     assert rel_err(xg.grad, xr.grad) < tol
-    assert rel_err(wg.grad, wr.grad) < max(tol, 2e-5)
+    wtol = max(tol, 2e-5)
+    if precision == 'f16c8' and mode in ('up', 'down') and ops.L.load().eovae_get_option(b'c8_wgrad_corr') == 0:
+        # round 5: the row-streaming weight gradients (here: the sub-pixel forms) multiply f16(dY) * f16(X) alone -- two f16
+        # roundings per term, which on this test's incoherent data is ~3e-4 of the largest entry.  That the kernel computes
+        # EXACTLY those products is pinned in tests/test_gpu_wgrad_rows.py (float64 sum of the same products, 3e-6).
+        wtol = 5e-4
+    assert rel_err(wg.grad, wr.grad) < wtol
     assert rel_err(bg.grad, br.grad) < 2e-5      # fp32 sums of dy (fused into the wgrad kernel)
 
 
@@ -202,6 +208,13 @@ def test_groupnorm_operand_records_equal_the_fp32_hand_over(n, c, cout, h, w):
     from eo_vae_amd import ops
     old = ops.CONV_PRECISION
     ops.CONV_PRECISION = 'f16c8'
+    lib = ops.L.load()
+    # "the same result" holds for the same arithmetic: the fp32 hand-over runs the fp8 correction product in the forward
+    # and in the weight gradient, so the records get the same here (round 5's defaults for records -- MX-FP6 forward, plain
+    # f16 weight gradient -- are pinned in tests/test_gpu_mx.py and tests/test_gpu_wgrad_rows.py)
+    keep = {k: lib.eovae_get_option(k) for k in (b'c8_mx', b'c8_wgrad_corr')}
+    lib.eovae_set_option(b'c8_mx', 0)
+    lib.eovae_set_option(b'c8_wgrad_corr', 1)
     try:
         x = hashed((n, c, h, w), 11, 1.0)
         gam, bet = 1.0 + hashed((c,), 12, 0.2), hashed((c,), 13, 0.2)
@@ -228,6 +241,8 @@ def test_groupnorm_operand_records_equal_the_fp32_hand_over(n, c, cout, h, w):
                        hashed((cout, c, 1, 1), 17, 0.1).cuda(), None, None, 'normal')
     finally:
         ops.CONV_PRECISION = old
+        for k, v in keep.items():
+            lib.eovae_set_option(k, v)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,res,mode', [
