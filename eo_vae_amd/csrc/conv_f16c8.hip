@@ -81,8 +81,11 @@ __device__ unsigned long long c8_stamps[C8_NBLK * 8 * C8_MAXREC * C8_NPT];
 #ifndef EOVAE_C8_ABL
 #define EOVAE_C8_ABL 0   // timing-only experiments: 1 few stores, 2 no halo loads, 4 no conversion, 8 no weight DMA, 16 no MFMAs
 #endif
-template <int TH, int SUBPIX, bool PACKED>
+// MX (round 5, PACKED only): x = MX operand records (format 2: F plane a.x, S plane a.x6; groupnorm.hip gn_apply_mx_kernel) and
+// the correction product runs on block-scaled FP6 operands (conv_f16c8_common.h), as in conv_f16c8_w4.hip.
+template <int TH, int SUBPIX, bool PACKED, bool MX = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
+  static_assert(!MX || (PACKED && SUBPIX == 0), "MX: record input of a plain 3x3 layer");
   constexpr int NW = 8, TW = 32, BM = 128, KC = 32, NTHR = NW * 64;
   constexpr int XH = TH + 2, XW = TW + 2, NPX = XH * XW;
   constexpr int NI = TH / (NW / 2);             // pixel-row tiles per wave
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       }
       xokm |= (si >= 0 ? 1u : 0u) << i;
       // BYTE offset: scalar base + 32-bit lane offset is one instruction (saddr form), no 64-bit lane address
-      xoff[i] = PACKED ? 32u * ((unsigned)(tk < XTASKS ? g : 0) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0))
+      xoff[i] = PACKED ? (MX ? 16u : 32u) * ((unsigned)(tk < XTASKS ? g : 0) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0))
                        : 4u * ((unsigned)((tk < XTASKS ? g : 0) * 8) * (unsigned)in_plane + (unsigned)(si >= 0 ? si : 0));
     }
   };
@@ -212,9 +215,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       cbase = c0 - par * a.creal;
       poff = (par >> 1) * a.Win + (par & 1);
     }
-    if (PACKED) {   // group j (0, 1) = the j-th 16 bytes of every task's record
-      const char* cj = reinterpret_cast<const char*>(a.x) +
-                       (((size_t)t.n * (xch / 8) + cbase / 8) * in_plane) * 32 + 16 * j;
+    if (PACKED) {   // group j (0, 1) = the j-th 16 bytes of every task's record (MX: its F-plane octet | its S-plane piece)
+      const char* cj = MX ? (j == 0 ? reinterpret_cast<const char*>(a.x) + (((size_t)t.n * (xch / 8) + cbase / 8) * in_plane) * 16
+                                    : reinterpret_cast<const char*>(a.x6) + (((size_t)t.n * (xch / 32) + cbase / 32) * 4 * in_plane) * 16)
+                          : reinterpret_cast<const char*>(a.x) +
+                                (((size_t)t.n * (xch / 8) + cbase / 8) * in_plane) * 32 + 16 * j;
 #pragma unroll
       for (int i = 0; i < XPT; ++i) {
         const f32x4 q = *reinterpret_cast<const f32x4*>(cj + xoff[i]);
@@ -254,8 +259,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
           lv[0] = __builtin_bit_cast(int, xr[i][4]) & keep; lv[1] = __builtin_bit_cast(int, xr[i][5]) & keep;
           uv[0] = __builtin_bit_cast(int, xr[i][6]) & keep; uv[1] = __builtin_bit_cast(int, xr[i][7]) & keep;
           *reinterpret_cast<i32x4*>(xsm + xst16[i]) = hv;
-          *reinterpret_cast<i32x2*>(xsm + xst8[i]) = lv;
-          *reinterpret_cast<i32x2*>(xsm + xst8[i] + 2 * NPX * 16) = uv;
+          if constexpr (MX) {   // the task's 16-byte piece of the pixel's FP6 block: image [part][piece][pixel] = [octet g][pixel]
+            i32x4 pv;
+            pv[0] = lv[0]; pv[1] = lv[1]; pv[2] = uv[0]; pv[3] = uv[1];
+            *reinterpret_cast<i32x4*>(xsm + XF16 + xst16[i]) = pv;
+          } else {
+            *reinterpret_cast<i32x2*>(xsm + xst8[i]) = lv;
+            *reinterpret_cast<i32x2*>(xsm + xst8[i] + 2 * NPX * 16) = uv;
+          }
         }
         continue;
       }
@@ -362,8 +373,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int piece = (wave * 2 + u) * 1024;
+        // MX: the slot's second half is the tile's FP6 part (waves 4..7 = pieces 8..15)
+        const int spiece = (MX && wave >= 4) ? piece + (C8_WOFF6 - C8_WOFF8) : piece;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
+            (const __attribute__((address_space(1))) void*)(src + spiece + lane * 16),
             (__attribute__((address_space(3))) void*)(smem + OFF_W + (half * 2 + tt) * WTAP + piece), 16, 0, 0);
       }
     }
@@ -422,6 +435,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
       f.b[j] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   };
+  // MX: keeps each FP6 fragment one eight-register tuple (data = dwords 0..5, scale = dword 6 as sub-registers); see
+  // conv_f16c8_w4.hip
+  auto pin8 = [&](Frag8& f) __attribute__((always_inline)) {
+    if constexpr (MX) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm("" : "+v"(f.a[i]));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm("" : "+v"(f.b[j]));
+    }
+  };
   auto mma16 = [&](const Frag16& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NI; ++j)
@@ -435,9 +458,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.a[i], f.b[j], acc[i][j], 0 /* A: e4m3 */,
-                                                                    1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (MX)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.a[i], f.b[j], acc[i][j], 2 /* A: e2m3 */,
+                                                                      2 /* B: e2m3 */, 0, f.a[i][6], 0, f.b[j][6]);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.a[i], f.b[j], acc[i][j], 0 /* A: e4m3 */,
+                                                                      1 /* B: e5m2 */, 0, sc_a, 0, sc_b);
+      }
   };
 
   // GroupNorm partial sums of a stored tile (a.gn_sums): gslot[wave][sum|sumsq][batch (i, qq)][quad of lanes] is
@@ -705,6 +733,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (two) load16(f16a, wslot + WTAP, xsel, ky1, kx1);
             __builtin_amdgcn_sched_barrier(0);
+            pin8(f8a);
             mma8(f8a);
             __builtin_amdgcn_sched_barrier(0);
             if (wave >= 4) stage_dma();
@@ -714,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16c8_kernel(ConvCArgs a) {
               __builtin_amdgcn_sched_barrier(0);
               mma16(f16a);
               __builtin_amdgcn_sched_barrier(0);
+              pin8(f8a);
               mma8(f8a);
               __builtin_amdgcn_sched_barrier(0);
               stage_loads(1);
@@ -1926,7 +1956,10 @@ int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, c
                                int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups,
                                unsigned* out_amax, void* stream) {
   EOVAE_CHECK_ARG(x && wp && y, "conv3x3_f16c8_fwd: null pointer");
-  EOVAE_CHECK_ARG(!x6 || xpacked, "conv3x3_f16c8_fwd_mx: an FP6 plane belongs to a record input");
+  EOVAE_CHECK_ARG(xpacked >= 0 && xpacked <= 2, "conv3x3_f16c8_fwd: xpacked %d (0 fp32, 1 operand records, 2 MX operand records)", xpacked);
+  EOVAE_CHECK_ARG(xpacked != 2 || Cin % 32 == 0, "conv3x3_f16c8_fwd: MX operand records need Cin %% 32 == 0");
+  if (xpacked == 2 && !x6) x6 = reinterpret_cast<const char*>(x) + (size_t)N * Cin * Hin * Win * 2;   // S plane behind the F plane
+  EOVAE_CHECK_ARG(!x6 || xpacked == 2, "conv3x3_f16c8_fwd_mx: an FP6 plane belongs to MX operand records (xpacked = 2)");
   EOVAE_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv3x3_f16c8_fwd: bad shape");
   EOVAE_CHECK_ARG(mode == MODE_NORMAL, "conv3x3_f16c8_fwd: mode %d unsupported (stride-1 'normal' layers and the "
                   "sub-pixel / space-to-depth forms only)", mode);
@@ -2013,7 +2046,8 @@ int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, c
 #define EOVAE_LAUNCH_C8(TH)                                                                                   \
   switch (subpix) {                                                                                           \
     case 0:                                                                                                   \
-      if (xpacked) hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0, true>), grid, blk, 0, st, a);                \
+      if (xpacked == 2) hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0, true, true>), grid, blk, 0, st, a);     \
+      else if (xpacked) hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0, true>), grid, blk, 0, st, a);           \
       else hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 0, false>), grid, blk, 0, st, a);                       \
       break;                                                                                                  \
     case 1: hipLaunchKernelGGL((conv3x3_f16c8_kernel<TH, 1, false>), grid, blk, 0, st, a); break;             \
@@ -2041,6 +2075,7 @@ static int c8_wgrad_impl(const float* x, const float* dy, float* dwp, float* par
   EOVAE_CHECK_ARG(mode == MODE_NORMAL || mode == MODE_UP, "conv3x3_f16c8_wgrad: mode %d unsupported", mode);
   EOVAE_CHECK_ARG(!xpacked || (subpix == 0 && mode == MODE_NORMAL && Cin % 64 == 0),
                   "conv3x3_f16c8_wgrad: packed x needs a plain layer with Cin %% 64 == 0");
+  EOVAE_CHECK_ARG(xpacked >= 0 && xpacked <= 2, "conv3x3_f16c8_wgrad: xpacked %d", xpacked);
   WgCArgs a;
   EOVAE_CHECK_ARG(!(xpacked && xamax), "conv3x3_f16c8_wgrad: operand records carry no scale (xamax must be NULL)");
   a.x = x; a.dy = dy; a.dwp = dwp; a.db = db; a.dyamax = dyamax; a.xamax = xamax; a.part = part;
@@ -2071,7 +2106,7 @@ static int c8_wgrad_impl(const float* x, const float* dy, float* dwp, float* par
   a.xpacked = xpacked;
   a.nseg = 1; a.units = 0;
   // one-wave-per-SIMD kernel (conv_f16c8_wgrad_w4.hip) for plain layers made of full tiles
-  if (!part && eovae_c8_wgrad_w4_eligible(a)) {
+  if (!part && xpacked != 2 && eovae_c8_wgrad_w4_eligible(a)) {
     eovae_c8_wgrad_w4_launch(a, st);
     EOVAE_CHECK_LAUNCH("eovae_conv3x3_f16c8_wgrad (w4)");
     return EOVAE_OK;
@@ -2080,6 +2115,11 @@ static int c8_wgrad_impl(const float* x, const float* dy, float* dwp, float* par
   if (eovae_c8_wgrad_rows_eligible(a)) {
     eovae_c8_wgrad_rows_launch(a, st);
     split = a.split;
+  } else if (xpacked == 2) {
+    eovae_set_error("conv3x3_f16c8_wgrad: MX operand records (xpacked = 2) are read by the row-streaming weight gradient only "
+                    "(plain layer, Cout %% 128 == 0, Cin %% 64 == 0, W %% 32 == 0, options c8_wgrad_rows = 1, c8_wgrad_corr = 0): ask "
+                    "eovae_records_mx_ok() before writing them");
+    return EOVAE_ERR_UNSUPPORTED;
   } else
   if (subpix == 1) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<1, false>), grid, dim3(512), 0, st, a);
   else if (subpix == 2) hipLaunchKernelGGL((wgrad3x3_f16c8_kernel<2, false>), grid, dim3(512), 0, st, a);
@@ -2099,6 +2139,18 @@ int eovae_conv3x3_f16c8_wgrad(const float* x, const float* dy, float* dwp, float
                               int mode, int subpix, int xpacked, void* stream) {
   return c8_wgrad_impl(x, dy, dwp, nullptr, nullptr, db, dyamax, xamax, N, Cin, Hin, Win, Cout, Hout, Wout, mode, subpix,
                        xpacked, stream);
+}
+
+// 1 when a GroupNorm whose only consumer is the plain 3x3 layer (N, Cin, H, W) -> Cout may hand its result over as MX
+// operand records (eovae_gn_silu_fwd_packed_mx, xpacked = 2): the forward kernels read them whenever Cin % 32 == 0; the weight
+// gradient must be the row-streaming kernel in its f16 form.  0: write format-1 records (eovae_gn_silu_fwd_packed).
+int eovae_records_mx_ok(int N, int Cin, int H, int W, int Cout) {
+  if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  if (!eovae_opt(EOVAE_OPT_C8_MX) || eovae_opt(EOVAE_OPT_C8_WGRAD_CORR)) return 0;
+  WgCArgs a;
+  a.part = reinterpret_cast<float*>(1); a.subpix = 0; a.mode = MODE_NORMAL; a.xpacked = 2; a.xamax = nullptr;
+  a.N = N; a.Cin = Cin; a.Hin = H; a.Win = W; a.Cout = Cout; a.Hout = H; a.Wout = W;
+  return eovae_c8_wgrad_rows_eligible(a) ? 1 : 0;
 }
 
 // bytes of scratch eovae_conv3x3_f16c8_wgrad_dw needs: one [9][128][64] fp32 tile per block of the launch

@@ -75,8 +75,9 @@ __device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
 // MX (round 5): the correction product on block-scaled FP6 operands (conv_f16c8_common.h) -- phases 9..17 run 16 x
 // v_mfma_scale_f32_32x32x64_f8f6f4 with e2m3 operands (~0.6 x the cycles of the fp8 form), each lane's scale byte riding in
 // dword 6 of its fragment.  Same LDS images, same fragment reads (the 32 FP6 bytes of a lane = 24 data + scale + pad sit
-// where its 32 fp8 bytes sat).  Record input: the FP6 pieces come from the records' MX plane (a.x6:
-// [n][Cin / 32][piece 0..3][pixel][16 B], piece = wave), one 16-byte load and one 16-byte LDS store per task.
+// where its 32 fp8 bytes sat).  The input is then MX operand records (format 2, groupnorm.hip gn_apply_mx_kernel): the f16
+// octets from the F plane (a.x: [n][Cin / 8][pixel][16 B]), the FP6 pieces from the S plane (a.x6: [n][Cin / 32][piece
+// 0..3][pixel][16 B], piece = wave) -- two 16-byte loads and two 16-byte LDS stores per task.
 template <bool PACKED, int NI, bool MX>
 __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   static_assert(!MX || PACKED, "MX: record input only (the fp32 staging path follows)");
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   const int sc_b = e8m0(0);
 
   // ---------------------------------------------------------------- halo staging (wave = channel octet)
-  constexpr unsigned UNIT = PACKED ? 32u : 4u;   // bytes per pixel step of the source (records / fp32 plane)
+  constexpr unsigned UNIT = MX ? 16u : (PACKED ? 32u : 4u);   // bytes per pixel step of the source (MX planes / records / fp32 plane)
   float xr[NTASK][8];
   unsigned xoff[NTASK];
   unsigned xokm = 0;
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     const long origin = (long)(t.oy0 - 1) * a.Win + (t.ox0 - 1);
     if (PACKED)
       return reinterpret_cast<const char*>(a.x) +
-             (((long)t.n * (a.Cin / 8) + c0 / 8 + wave) * (long)in_plane + origin) * 32;
+             (((long)t.n * (a.Cin / 8) + c0 / 8 + wave) * (long)in_plane + origin) * (long)UNIT;
     return reinterpret_cast<const char*>(a.x) + (((long)t.n * a.Cin + c0 + 8 * wave) * (long)in_plane + origin) * 4;
   };
-  // MX: piece `wave` of the chunk's FP6 plane, 16 bytes per pixel (= half a record's pixel step: offsets xoff / 2)
+  // MX: piece `wave` of the chunk's FP6 plane, 16 bytes per pixel (the same offsets as the F plane)
   auto x6base = [&](const Tile& t, int c0) __attribute__((always_inline)) {
     const long origin = (long)(t.oy0 - 1) * a.Win + (t.ox0 - 1);
     return reinterpret_cast<const char*>(a.x6) +
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     for (int k = 0; k < NTASK; ++k) {
       if (PACKED) {
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(xb + xoff[k]);
-        const f32x4 q1 = MX ? *reinterpret_cast<const f32x4*>(x6b + (xoff[k] >> 1))
+        const f32x4 q1 = MX ? *reinterpret_cast<const f32x4*>(x6b + xoff[k])
                             : *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { xr[k][c] = q0[c]; xr[k][4 + c] = q1[c]; }
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
 #pragma unroll
               for (int k = k0; k < k0 + TPP && k < NTASK; ++k) {
                 if (((k - k0) & 3) != i) continue;
-                const f32x4 qv = (MX && half) ? *reinterpret_cast<const f32x4*>(x6b + (xoff[k] >> 1))
+                const f32x4 qv = (MX && half) ? *reinterpret_cast<const f32x4*>(x6b + xoff[k])
                                               : *reinterpret_cast<const f32x4*>(xb + xoff[k] + 16 * half);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xr[k][4 * half + c] = qv[c];
@@ -651,7 +652,7 @@ extern "C" int eovae_debug_w4_stamps(void* dst, size_t bytes) {
 // variant spills 50 registers into the phase sequence and is not used.
 static int w4_rows_per_wave(const ConvCArgs& a, int n_cu) {
   (void)n_cu;
-  if (eovae_opt(EOVAE_OPT_C8_W4_NI) == 2 && a.packed && a.Hout % 8 == 0) return 2;
+  if (eovae_opt(EOVAE_OPT_C8_W4_NI) == 2 && a.packed == 1 && a.Hout % 8 == 0) return 2;
   return a.Hout % 16 == 0 ? 4 : 0;
 }
 
@@ -679,7 +680,7 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   a.skew = ni == 2 ? (sk >= 0 ? sk : (a.nchunk * 7 + 2) / 5) : 0;
   const int nblk = ni == 2 ? 2 * n_cu : n_cu;
   const dim3 grid((unsigned)(a.ntiles < nblk ? a.ntiles : nblk)), blk(256);
-  a.mx = (a.packed && a.x6 && ni == 4 && eovae_opt(EOVAE_OPT_C8_MX) != 0) ? 1 : 0;
+  a.mx = a.packed == 2 ? 1 : 0;   // MX operand records (format 2): their FP6 plane is the only correction operand they carry
   if (ni == 2) {
     if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 2, false>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 2, false>), grid, blk, 0, st, a);

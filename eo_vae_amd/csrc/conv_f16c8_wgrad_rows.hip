@@ -206,7 +206,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   // the per-lane DMA offset change only when a unit opens.
   const int segrows = uni(H / a.nseg);
   const unsigned OOR = 0x80000000u;
-  const unsigned dyspan = (unsigned)a.Cout * dplane * 4u, xspan = 8u * plane * 32u;
+  // bytes per pixel and channel octet of X: 32 = operand records (format 1: f16 | e5m2 halves), 16 = the F plane of MX operand
+  // records (format 2: f16 only -- !CORR; groupnorm.hip gn_apply_mx_kernel)
+  const unsigned XU = (!CORR && a.xpacked == 2) ? 16u : 32u;
+  const unsigned dyspan = (unsigned)a.Cout * dplane * 4u, xspan = 8u * plane * XU;
   struct Cursor {
     int R, r0, r1, live;
     unsigned xsoff, dsoff;     // byte offsets of X row R / of dY row R + 1 at the strip's first column (scalar offsets)
@@ -229,17 +232,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
         c.r0 = uni(seg * segrows);
         c.r1 = c.r0 + segrows;
         c.R = c.r0 - 1;
-        c.xsoff = (unsigned)uni((c.R * W) * 32);
+        c.xsoff = (unsigned)uni((c.R * W) * (int)XU);
         c.dsoff = SP ? (unsigned)uni(((2 * (c.r0 - py) + py) * 2 * W + 2 * x0) * 4) : (unsigned)uni((c.r0 * W + x0) * 4);
-        c.xbase = uni_ptr(reinterpret_cast<const char*>(a.x) + ((size_t)n * (a.Cin / 8) + (size_t)cib * 8) * plane * 32);
+        c.xbase = uni_ptr(reinterpret_cast<const char*>(a.x) + ((size_t)n * (a.Cin / 8) + (size_t)cib * 8) * plane * XU);
         c.dbase = uni_ptr(a.dy + (size_t)n * a.Cout * dplane);
         const unsigned ln = threadIdx.x & 63u;
         const int px = x0 - 1 + (int)ln;
-        vx = (ln < 34u && (unsigned)px < (unsigned)W) ? ((unsigned)wave * plane + (unsigned)px) * 32u : OOR;
+        vx = (ln < 34u && (unsigned)px < (unsigned)W) ? ((unsigned)wave * plane + (unsigned)px) * XU : OOR;
       }
     } else {
       ++c.R;
-      c.xsoff += (unsigned)(W * 32);
+      c.xsoff += (unsigned)W * XU;
       c.dsoff += (unsigned)((SP ? 4 : 1) * W * 4);
     }
   };
@@ -813,6 +816,7 @@ __global__ __launch_bounds__(576) void wgrad_down_fold_kernel(const float* __res
 }  // namespace
 
 bool eovae_c8_wgrad_rows_eligible(const WgCArgs& a) {
+  if (a.xpacked == 2 && eovae_opt(EOVAE_OPT_C8_WGRAD_CORR)) return false;   // MX operand records carry no e5m2 parts
   return eovae_opt(EOVAE_OPT_WGRAD_ROWS) != 0 && a.part && a.subpix == 0 && a.mode == MODE_NORMAL && a.xpacked && a.Cout % 128 == 0 &&
          a.Cin % 64 == 0 && a.Wout % 32 == 0 && a.Hout >= 1 && !a.xamax &&
          (long long)a.Hout * a.Wout * 32 * 8 < (1LL << 31) && (long long)a.Cout * a.Hout * a.Wout * 4 < (1LL << 32);

@@ -187,20 +187,21 @@ __global__ __launch_bounds__(256) void gn_apply_packed_kernel(const float* __res
   rec[1] = a1;
 }
 
-// stage 3, f16c8 operand form WITH the MX-FP6 plane (round 5): as gn_apply_packed_kernel, and besides the records
-//   p6[n][C/32][piece 0..3][HW] x 16 B : the block-scaled FP6 (e2m3) operands of the forward convolution's correction
-//   product for channels 32 b .. 32 b + 31 of a pixel -- pieces 0, 1 = (y - f16(y)) ("lo", pairs with the weights' leading
-//   part), pieces 2, 3 = y ("hi", pairs with the weights' residual part); layout of a block: conv_f16c8_common.h.
+// stage 3, MX operand records (round 5, "format 2"): normalise + affine + silu, written as the operands of a plain 3x3 layer
+// whose forward runs the MX-FP6 correction product and whose weight gradient multiplies f16 x f16 alone
+// (conv_f16c8_common.h, conv_f16c8_wgrad_rows.hip) -- still 4 B per element, in two planes inside pa:
+//   F  pa[n][C/8][HW] x 16 B              : 8 x f16 y                          (channels 8 g .. 8 g + 7)
+//   S  pa + N*C*HW*2 B : [n][C/32][piece 0..3][HW] x 16 B : the block-scaled e2m3 operands of channels 32 b .. 32 b + 31 of a
+//      pixel -- pieces 0, 1 = (y - f16(y)) ("lo", pairs with the weights' leading part), pieces 2, 3 = y ("hi", pairs with
+//      the weights' residual part); a block = 6 dwords of 32 x 6 bits + its E8M0 scale byte in dword 6.
+// The e5m2 parts of format 1 are gone: nothing reads them any more (the weight gradient needs the f16 parts only).
 // The scale of a block is shared by the 32 channels of ONE pixel (the K axis of the forward convolution), so a thread owns
-// a pixel x 32 channels: 32 coalesced dword loads, 8 + 4 sixteen-byte stores; grid = N * C/32 * ceil(HW / 256).
-// The records keep their e5m2 parts: the weight gradient multiplies along the PIXEL axis and still runs on them.
+// a pixel x 32 channels: 32 coalesced dword loads, 4 + 4 sixteen-byte stores; grid = N * C/32 * ceil(HW / 256).
 template <bool SILU, bool FROM_SUMS>
 __global__ __launch_bounds__(256) void gn_apply_mx_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ stats,
                                                           const double* __restrict__ sums, double inv_count, float eps,
-                                                          int* __restrict__ pa, int* __restrict__ p6, int C, int HW, int cpg,
-                                                          int pblocks) {
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
+                                                          int* __restrict__ pa, int N, int C, int HW, int cpg, int pblocks) {
   const int pb = blockIdx.x % pblocks, bg = blockIdx.x / pblocks;   // bg = n * C/32 + block
   const int blk = bg % (C / 32), n = bg / (C / 32);
   const int p = pb * 256 + threadIdx.x;
@@ -234,15 +235,15 @@ __global__ __launch_bounds__(256) void gn_apply_mx_kernel(const float* __restric
   const float* xp = x + ((size_t)n * C + blk * 32) * HW + p;
 #pragma unroll
   for (int j = 0; j < 32; ++j) v[j] = xp[(size_t)j * HW];
-  float ah = 0.f, al = 0.f;
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     const float o = v[j] * st_s[j][0] + st_s[j][1];
     v[j] = SILU ? silu_f(o) : o;
   }
+  i32x4* fpl = reinterpret_cast<i32x4*>(pa) + ((size_t)n * (C / 8) + blk * 4) * HW + p;
 #pragma unroll
   for (int oc = 0; oc < 4; ++oc) {
-    int pk[4];
+    i32x4 pk;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
       int hh;
@@ -252,31 +253,16 @@ __global__ __launch_bounds__(256) void gn_apply_mx_kernel(const float* __restric
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[8 * oc + j + 1]) : "v"(hh), "v"(v1));
       pk[j >> 1] = hh;
     }
-    const float* l8 = lo + 8 * oc;
-    const float* v8 = v + 8 * oc;
-    s16x2 l0 = {0, 0}, l1 = {0, 0};
-    l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, l8[0], l8[1], 0x1p-12f, false);
-    l0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l0, l8[2], l8[3], 0x1p-12f, true);
-    l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, l8[4], l8[5], 0x1p-12f, false);
-    l1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(l1, l8[6], l8[7], 0x1p-12f, true);
-    int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[0], v8[1], 0, false);
-    h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[2], v8[3], h0, true);
-    int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[4], v8[5], 0, false);
-    h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v8[6], v8[7], h1, true);
-    i32x4 a0, a1;
-    a0[0] = pk[0]; a0[1] = pk[1]; a0[2] = pk[2]; a0[3] = pk[3];
-    a1[0] = __builtin_bit_cast(int, l0); a1[1] = __builtin_bit_cast(int, l1); a1[2] = h0; a1[3] = h1;
-    i32x4* rec = reinterpret_cast<i32x4*>(pa + (((size_t)n * (C / 8) + blk * 4 + oc) * HW + p) * 8);
-    rec[0] = a0;
-    rec[1] = a1;
+    fpl[(size_t)oc * HW] = pk;
   }
+  float ah = 0.f, al = 0.f;
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     ah = fmaxf(ah, fabsf(v[j]));
     al = fmaxf(al, fabsf(lo[j]));
   }
   i32x4 q0, q1;
-  i32x4* dst = reinterpret_cast<i32x4*>(p6) + ((size_t)bg * 4) * HW + p;
+  i32x4* dst = reinterpret_cast<i32x4*>(reinterpret_cast<char*>(pa) + (size_t)N * C * HW * 2) + ((size_t)bg * 4) * HW + p;
   mx6_quant(lo, al, q0, q1);
   dst[0] = q0;
   dst[(size_t)HW] = q1;
@@ -1068,12 +1054,13 @@ int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* be
   return EOVAE_OK;
 }
 
-// As eovae_gn_silu_fwd_packed, and besides the records the MX-FP6 plane of the forward convolution's correction product
-// (gn_apply_mx_kernel): p6 has N*C*HW/2 dwords (2 bytes per element), C must be a multiple of 32.
-int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float* beta, void* pa, void* p6, float* stats,
+// As eovae_gn_silu_fwd_packed, but the output is written as MX operand records ("format 2", gn_apply_mx_kernel): pa has
+// N*C*HW dwords -- the f16 plane in its first half, the MX-FP6 plane in its second; C must be a multiple of 32.  Consumers:
+// eovae_conv3x3_f16c8_fwd_mx / the f16c8 weight-gradient entries with xpacked = 2.
+int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
                                 const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
                                 void* stream) {
-  EOVAE_CHECK_ARG(x && gamma && beta && pa && p6 && stats && ws, "gn_silu_fwd_packed_mx: null pointer");
+  EOVAE_CHECK_ARG(x && gamma && beta && pa && stats && ws, "gn_silu_fwd_packed_mx: null pointer");
   EOVAE_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C % 32 == 0, "gn_silu_fwd_packed_mx: C=%d G=%d", C, G);
   hipStream_t st = (hipStream_t)stream;
   const int cpg = C / G;
@@ -1086,10 +1073,10 @@ int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float*
   if (sums) {
     if (silu)
       hipLaunchKernelGGL((gn_apply_mx_kernel<true, true>), grid, dim3(256), 0, st, x, gamma, beta, stats, sums, inv_count, eps,
-                         (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+                         (int*)pa, N, C, HW, cpg, pblocks);
     else
       hipLaunchKernelGGL((gn_apply_mx_kernel<false, true>), grid, dim3(256), 0, st, x, gamma, beta, stats, sums, inv_count, eps,
-                         (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+                         (int*)pa, N, C, HW, cpg, pblocks);
     EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed_mx");
     return EOVAE_OK;
   }
@@ -1097,10 +1084,10 @@ int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float*
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, part, stats, N * G, ns, inv_count, eps);
   if (silu)
     hipLaunchKernelGGL((gn_apply_mx_kernel<true, false>), grid, dim3(256), 0, st, x, gamma, beta, stats, (const double*)nullptr,
-                       inv_count, eps, (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+                       inv_count, eps, (int*)pa, N, C, HW, cpg, pblocks);
   else
     hipLaunchKernelGGL((gn_apply_mx_kernel<false, false>), grid, dim3(256), 0, st, x, gamma, beta, stats,
-                       (const double*)nullptr, inv_count, eps, (int*)pa, (int*)p6, C, HW, cpg, pblocks);
+                       (const double*)nullptr, inv_count, eps, (int*)pa, N, C, HW, cpg, pblocks);
   EOVAE_CHECK_LAUNCH("eovae_gn_silu_fwd_packed_mx");
   return EOVAE_OK;
 }

@@ -32,14 +32,15 @@ class GroupNorm(nn.GroupNorm):
         super().__init__(num_groups=groups, num_channels=channels, eps=1e-6, affine=True)
         self.silu = silu
 
-    def forward(self, x, packed=False):
+    def forward(self, x, packed=False, cout=None):
         """packed=True: the caller feeds the result to a plain 3x3 Conv2d and nothing else; in f16c8 mode it is then
-        produced as that kernel's operand records instead of fp32 (ops.mark_packed)."""
-        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, self.silu, packed)
+        produced as that kernel's operand records instead of fp32 (ops.mark_packed).  cout: that layer's output channels
+        (MX operand records where the layer takes them, ops.records_format_for)."""
+        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, self.silu, packed, cout)
 
-    def forward_fork(self, x, packed=False):
+    def forward_fork(self, x, packed=False, cout=None):
         """-> (normalised+activated x, x for the residual branch); see ops.GroupNormSiluForkFn."""
-        return ops.group_norm_silu_fork(x, self.weight, self.bias, self.num_groups, self.eps, self.silu, packed)
+        return ops.group_norm_silu_fork(x, self.weight, self.bias, self.num_groups, self.eps, self.silu, packed, cout)
 
 
 class Downsample(nn.Module):  # layers.py:25-37
@@ -78,10 +79,11 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x, emb=None):
-        a, xs = self.norm1.forward_fork(x, packed=True)        # conv1 / conv2 are the only consumers of the
-        h = self.conv1(a)                                      # two GroupNorm outputs: operand records
+        # conv1 / conv2 are the only consumers of the two GroupNorm outputs: operand records
+        a, xs = self.norm1.forward_fork(x, packed=True, cout=self.out_channels)
+        h = self.conv1(a)
         skip = self.nin_shortcut(xs) if self.in_channels != self.out_channels else xs
-        return self.conv2(self.norm2(h, packed=True), residual=skip)
+        return self.conv2(self.norm2(h, packed=True, cout=self.out_channels), residual=skip)
 
 
 class AttnBlock(nn.Module):

@@ -43,7 +43,8 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_wgrad_dw_workspace': (_sz, [_i, _i]),
     'eovae_conv3x3_f16c8_wgrad_dw': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     'eovae_gn_silu_fwd_packed': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
-    'eovae_gn_silu_fwd_packed_mx': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
+    'eovae_gn_silu_fwd_packed_mx': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
+    'eovae_records_mx_ok': (_i, [_i, _i, _i, _i, _i]),
     'eovae_subpix_expand': (_i, [_p, _p, _i, _i, _p]),
     'eovae_down_expand': (_i, [_p, _p, _i, _i, _i, _p]),
     'eovae_down_fold': (_i, [_p, _p, _i, _i, _p]),

@@ -233,22 +233,58 @@ def packed_ok(channels):
 PACKED_ACTIVATIONS = os.environ.get('EOVAE_PACKED_ACT', '1') != '0'
 
 
-# Round 5: operand records can carry a second plane -- the MX-FP6 (block-scaled e2m3) operands of the forward convolution's
-# correction product (csrc/groupnorm.hip gn_apply_mx_kernel, 2 bytes per element, alive from the GroupNorm to the convolution
-# that consumes it).  It rides on the records tensor as `_eovae_mx = (plane, version)`; a consumer that does not find it (a
-# clone, a checkpointed re-use) multiplies with the records' e5m2 parts instead -- slower, never wrong.
-def mx_enabled():
-    return CONV_PRECISION == 'f16c8' and L.load().eovae_get_option(b'c8_mx') != 0
+# Round 5: MX operand records ("format 2", csrc/groupnorm.hip gn_apply_mx_kernel) -- the same 4 bytes per element in two
+# planes: 8 x f16 per pixel and channel octet, and per pixel and 32 channels the block-scaled FP6 (e2m3) operands of the
+# forward convolution's correction product.  Their consumers are the forward of a plain 3x3 layer (MX-FP6 correction
+# product, ~1.6 x the fp8 rate) and its weight gradient in the f16 form of the row-streaming kernel; the GroupNorm writes
+# them only when told which layer consumes its result (`cout=`) and the library says that layer takes them
+# (eovae_records_mx_ok).  A subclass again: the format survives detach() / clone() / views like the marking itself.
+class PackedRecordsMX(PackedRecords):
+    """MX operand records (f16 plane + MX-FP6 plane) in a float32 shell."""
 
 
-_LAST_MX = None   # handed from the GroupNorm Function's forward to group_norm_silu(), which tags the tensor autograd returns
+def mark_packed_mx(t):
+    return t if isinstance(t, PackedRecordsMX) else t.as_subclass(PackedRecordsMX)
 
 
-def mx_plane_of(x):
-    tag = getattr(x, '_eovae_mx', None)
-    if tag is not None and tag[1] == x._version and tag[0].device == x.device and tag[0].numel() * 2 == x.numel():
-        return tag[0]
-    return None
+def packed_format(t):
+    """0 = fp32 values, 1 = f16c8 operand records, 2 = MX operand records (the `xpacked` code of the C entries)."""
+    return 2 if isinstance(t, PackedRecordsMX) else (1 if isinstance(t, PackedRecords) else 0)
+
+
+def records_format_for(x, cout):
+    """Format a GroupNorm over x writes for a consumer that is a plain 3x3 layer with `cout` output channels (None / 0:
+    unknown consumer -> format 1, which every record consumer reads)."""
+    if not cout or CONV_PRECISION != 'f16c8':
+        return 1
+    n, c, h, w = x.shape
+    return 2 if L.load().eovae_records_mx_ok(n, c, h, w, int(cout)) == 1 else 1
+
+
+def mx_planes(t):
+    """(f16 plane, MX-FP6 plane) of MX operand records, as int32 views [N, C/8, HW, 4] and [N, C/32, 4, HW, 4] (tests, tools)."""
+    if not isinstance(t, PackedRecordsMX):
+        raise L.EovaeError('mx_planes: not MX operand records')
+    n, c, h, w = t.shape
+    with torch._C.DisableTorchFunctionSubclass():
+        raw = t.detach().as_subclass(torch.Tensor).reshape(-1).view(torch.int32)
+    half = raw.numel() // 2
+    return raw[:half].view(n, c // 8, h * w, 4), raw[half:].view(n, c // 32, 4, h * w, 4)
+
+
+def records_f16(t):
+    """The f16 leading parts an operand-record tensor (either format) holds, as a float32 [N, C, H, W] tensor (tests, tools)."""
+    fmt = packed_format(t)
+    if not fmt:
+        raise L.EovaeError('records_f16: not operand records')
+    n, c, h, w = t.shape
+    with torch._C.DisableTorchFunctionSubclass():
+        raw = t.detach().as_subclass(torch.Tensor).reshape(-1).view(torch.int32)
+    if fmt == 2:
+        f = raw[:raw.numel() // 2].view(n, c // 8, h * w, 4)
+    else:
+        f = raw.view(n, c // 8, h * w, 8)[..., :4].contiguous()
+    return f.view(torch.float16).view(n, c // 8, h * w, 8).permute(0, 1, 3, 2).reshape(n, c, h, w).float()
 
 
 # Every 3x3 convolution of the model is followed by a GroupNorm(32) over its output (layers.py:91-92, 106-108;
@@ -340,14 +376,14 @@ def _pack3x3(w4, rows, cols, flip, f16c8):
 
 
 def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix, f16c8, amax=None,
-               packed=False, gn_sums=None, out_amax=None, x6=None):
+               packed=0, gn_sums=None, out_amax=None):
     """out_amax (f16c8 only): a zeroed [1] int32 that receives the float bits of max|y| from the kernel's epilogue.
-    x6 (record input only): the records' MX-FP6 plane (mx_plane_of)."""
+    packed: 0 fp32 input, 1 operand records, 2 MX operand records (packed_format)."""
     lib = L.load()
     if packed and not f16c8:
         raise L.EovaeError('conv2d: operand-record input reached a non-f16c8 kernel')
     if f16c8:
-        L.check(lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(x), L.ptr(x6) if packed else None, L.ptr(wp), L.ptr(bias), L.ptr(residual),
+        L.check(lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(x), None, L.ptr(wp), L.ptr(bias), L.ptr(residual),
                                                L.ptr(y), L.ptr(amax), n, cin_g, h, w, cout_gemm, ho, wo, mode, subpix,
                                                int(packed), L.ptr(gn_sums), GN_GROUPS_HINT if gn_sums is not None else 0,
                                                L.ptr(out_amax), L.stream()), 'eovae_conv3x3_f16c8_fwd')
@@ -357,7 +393,7 @@ def _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode
                                            L.stream()), 'eovae_conv3x3_bf16_fwd')
 
 
-def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=False, xamax=None, dw=None):
+def _launch_wgrad3x3(x, dy, dwp, db, n, cin, h, w, cout, ho, wo, mode, subpix, packed=0, xamax=None, dw=None):
     """3x3 weight gradient into dwp (pre-zeroed): f16c8 kernel in f16c8 mode, else split-bf16.
     xamax: absmax bits of an fp32 x that is not a GroupNorm output (range_amax), or None."""
     lib = L.load()
@@ -491,7 +527,7 @@ def pack_pair_f16c8(weight):
     return wp0, wp1
 
 
-def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=False, wp=None, x6=None):
+def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, packed=0, wp=None):
     """3x3 stride-1 conv / data-gradient on the 16-bit matrix cores (weight in PyTorch layout).
     amax: absmax_bits(x) for a data-gradient call (x = dy) in f16c8 mode.  wp: an already packed weight."""
     cout, cin = weight.shape[0], weight.shape[1]
@@ -519,7 +555,7 @@ def conv3x3_lowp(x, weight, bias, residual, cout_gemm, mode, flip, amax=None, pa
     oa = None   # (forward outputs are not tagged: most come from the one-wave-per-SIMD kernel, whose epilogue has no
                 # register for a running maximum, and are read un-normalised by 6 of ~60 layers only)
     _launch3x3(x, wp, bias, residual, y, n, cin_g, h, w, cout_gemm, ho, wo, mode, 0, f8, None if packed else amax,
-               packed, sums, oa, x6)
+               packed, sums, oa)
     _LAST_GN_SUMS = sums
     _LAST_OUT_AMAX = oa
     if timed:
@@ -768,7 +804,7 @@ class Conv2dFn(torch.autograd.Function):
             raise L.EovaeError(f'conv2d: input has {x.shape[1]} channels, weight expects {cin}')
         res = _c(residual) if residual is not None else None
         bias_c = _c(bias) if bias is not None else None
-        packed = is_packed(x)
+        packed = packed_format(x)
         if packed and not (ks == 3 and m == MODE_NORMAL and CONV_PRECISION == 'f16c8'):
             raise L.EovaeError('conv2d: operand-record input (GroupNorm packed output) is only understood by the '
                                "plain 3x3 f16c8 convolution")
@@ -795,8 +831,7 @@ class Conv2dFn(torch.autograd.Function):
             # both weight orientations from one amax pass when the data gradient of this layer will be asked for
             if m == MODE_NORMAL and _use_f16c8(cin) and _use_f16c8(cout) and ctx.needs_input_grad[0]:
                 wp, ctx.wp_bwd = pack_pair_f16c8(weight)
-            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed, wp=wp,
-                             x6=mx_plane_of(x) if packed else None)
+            y = conv3x3_lowp(x, weight, bias_c, res, cout, m, False, packed=packed, wp=wp)
         elif ks == 1 and CONV_PRECISION != 'f32':
             y = conv1x1_lowp(x, weight, bias_c, res)
         else:
@@ -929,33 +964,20 @@ def conv2d(x, weight, bias=None, residual=None, mode='normal'):
 
 
 def _gn_forward(x, gamma, beta, groups, eps, silu, packed):
-    global _LAST_MX
+    """packed: 0 fp32 result, 1 operand records, 2 MX operand records."""
     n, c, h, w = x.shape
     lib = L.load()
     ws = workspace(lib.eovae_gn_workspace_bytes(n, c, h * w, groups), x.device)
     y = torch.empty_like(x)
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
-    _LAST_MX = None
-    if packed and c % 32 == 0 and mx_enabled():
-        p6 = torch.empty(x.numel() // 2, dtype=torch.float32, device=x.device)
-        L.check(lib.eovae_gn_silu_fwd_packed_mx(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(p6), L.ptr(stats),
-                                                L.ptr(gn_sums_of(x, groups)), n, c, h * w, groups, eps, int(silu), L.ptr(ws),
-                                                L.stream()), 'eovae_gn_silu_fwd_packed_mx')
-        _LAST_MX = p6
-        return y, stats
-    fn = lib.eovae_gn_silu_fwd_packed if packed else lib.eovae_gn_silu_fwd
+    fn = (lib.eovae_gn_silu_fwd, lib.eovae_gn_silu_fwd_packed, lib.eovae_gn_silu_fwd_packed_mx)[int(packed)]
     L.check(fn(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), L.ptr(gn_sums_of(x, groups)), n, c,
                h * w, groups, eps, int(silu), L.ptr(ws), L.stream()), 'eovae_gn_silu_fwd')
     return y, stats
 
 
-def _tag_mx(y):
-    """Attach the MX-FP6 plane the GroupNorm forward just wrote (if any) to the records tensor autograd returned."""
-    global _LAST_MX
-    if _LAST_MX is not None:
-        y._eovae_mx = (_LAST_MX, y._version)
-        _LAST_MX = None
-    return y
+def _mark(y, packed):
+    return mark_packed_mx(y) if packed == 2 else (mark_packed(y) if packed else y)
 
 
 class GroupNormSiluFn(torch.autograd.Function):
@@ -968,7 +990,7 @@ class GroupNormSiluFn(torch.autograd.Function):
         y, stats = _gn_forward(x, gamma, beta, groups, eps, silu, packed)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
-        return mark_packed(y) if packed else y
+        return _mark(y, packed)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1032,12 +1054,15 @@ def raise_on_gn_backward_timeouts():
                        'the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
 
 
-def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
+def group_norm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False, cout=None):
     """packed=True: the result is handed over as f16c8 operand records (see mark_packed) -- only for a
-    consumer that is a plain 3x3 Conv2dFn in f16c8 mode."""
-    packed = bool(packed and silu and packed_ok(x.shape[1]))
+    consumer that is a plain 3x3 Conv2dFn in f16c8 mode.  cout: that layer's output channels, if the caller knows them --
+    the records are then MX operand records where the layer takes them (records_format_for)."""
+    packed = int(bool(packed and silu and packed_ok(x.shape[1])))
+    if packed:
+        packed = records_format_for(x, cout)
     y = GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu, packed)
-    return _tag_mx(mark_packed(y)) if packed else y
+    return _mark(y, packed)
 
 
 class GroupNormSiluForkFn(torch.autograd.Function):
@@ -1052,7 +1077,7 @@ class GroupNormSiluForkFn(torch.autograd.Function):
         y, stats = _gn_forward(x, gamma, beta, groups, eps, silu, packed)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
-        return (mark_packed(y) if packed else y), x.view_as(x)
+        return _mark(y, packed), x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dskip):
@@ -1073,10 +1098,12 @@ class GroupNormSiluForkFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
-def group_norm_silu_fork(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False):
-    packed = bool(packed and silu and packed_ok(x.shape[1]))
+def group_norm_silu_fork(x, gamma, beta, groups=32, eps=1e-6, silu=True, packed=False, cout=None):
+    packed = int(bool(packed and silu and packed_ok(x.shape[1])))
+    if packed:
+        packed = records_format_for(x, cout)
     y, skip = GroupNormSiluForkFn.apply(x, gamma, beta, groups, eps, silu, packed)
-    return (_tag_mx(mark_packed(y)) if packed else y), skip
+    return _mark(y, packed), skip
 
 
 # ------------------------------------------------------------------------------------------

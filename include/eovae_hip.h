@@ -110,10 +110,11 @@ int eovae_conv3x3_f16c8_fwd_amax(const float* x, const void* wp, const float* bi
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups, unsigned* out_amax,
                             void* stream);
-/* as above; x6 (nullable; record input only) = the records' MX-FP6 plane written by eovae_gn_silu_fwd_packed_mx.  Kernels
- * that have the FP6 form (csrc/conv_f16c8_w4.hip) run the correction product [x_lo | x_hi].[w_hi | w_lo] on block-scaled
- * e2m3 operands (per-32-channel E8M0 scales, OCP MX) at ~1.6 x the fp8 rate; the others ignore it -- the records keep
- * their e5m2 parts.  Same call site as eovae_conv3x3_f16c8_fwd (F.conv2d of layers.py:64-66, 81-83). */
+/* as above, and the entry that understands xpacked = 2: x = MX operand records written by eovae_gn_silu_fwd_packed_mx (f16
+ * plane + MX-FP6 plane, see there); the correction product [x_lo | x_hi].[w_hi | w_lo] then runs on block-scaled e2m3
+ * operands (per-32-channel E8M0 scales, OCP MX) at ~1.6 x the fp8 rate.  x6 (nullable): the FP6 plane when it does not sit
+ * right behind the f16 plane (NULL: x + N*Cin*H*W*2 bytes).  Same call site as eovae_conv3x3_f16c8_fwd (F.conv2d of
+ * layers.py:64-66, 81-83). */
 int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, const float* bias, const float* residual,
                             float* y, const unsigned* xamax, int N, int Cin, int Hin, int Win, int Cout,
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups, unsigned* out_amax,
@@ -179,13 +180,19 @@ int eovae_amax_bound_from_sums(const double* sums, int n_groups, unsigned* out_b
 int eovae_gn_silu_fwd_packed(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
                              const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
                              void* stream);
-/* As eovae_gn_silu_fwd_packed, and besides the records the MX-FP6 plane p6[N][C/32][piece 0..3][HW] x 16 bytes
- * (N*C*HW/2 dwords; C %% 32 == 0): per pixel and 32 channels the block-scaled e2m3 operands of the forward convolution's
- * correction product -- pieces 0, 1 = (y - f16(y)), pieces 2, 3 = y; a block = 6 dwords of 32 x 6 bits + its E8M0 scale
- * byte in dword 6 (csrc/conv_f16c8_common.h).  Hand it to eovae_conv3x3_f16c8_fwd_mx as x6. */
-int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float* beta, void* pa, void* p6, float* stats,
+/* As eovae_gn_silu_fwd_packed, but the result is written as MX OPERAND RECORDS ("format 2", xpacked = 2 of the consumers;
+ * C %% 32 == 0; pa = N*C*HW dwords, the size of the fp32 activation): first half = f16 plane [N][C/8][HW] x 16 bytes (8 x f16
+ * y of channels 8g..8g+7), second half = MX-FP6 plane [N][C/32][piece 0..3][HW] x 16 bytes -- per pixel and 32 channels the
+ * block-scaled e2m3 operands of the forward convolution's correction product: pieces 0, 1 = (y - f16(y)), pieces 2, 3 = y; a
+ * block = 6 dwords of 32 x 6 bits + its E8M0 scale byte in dword 6 (csrc/conv_f16c8_common.h).  Consumers: the forward of a
+ * plain 3x3 layer (eovae_conv3x3_f16c8_fwd_mx) and its weight gradient in the f16 form of the row-streaming kernel
+ * (eovae_conv3x3_f16c8_wgrad_dw); ask eovae_records_mx_ok for the layer first. */
+int eovae_gn_silu_fwd_packed_mx(const float* x, const float* gamma, const float* beta, void* pa, float* stats,
                                 const double* sums, int N, int C, int HW, int G, float eps, int silu, void* ws,
                                 void* stream);
+/* 1 when the plain 3x3 layer (N, Cin, H, W) -> Cout takes MX operand records in its forward AND its weight gradient (shape of
+ * the row-streaming kernel; library options c8_mx = 1, c8_wgrad_rows = 1, c8_wgrad_corr = 0) */
+int eovae_records_mx_ok(int N, int Cin, int H, int W, int Cout);
 /* we[4*Cout][Cin][3][3] = parity-major sub-pixel expansion of w[Cout][Cin][3][3]; and its adjoint
  * dw[Cout][Cin][3][3] from dwp[9][4*Cout][Cin] */
 int eovae_subpix_expand(const float* w, float* we, int Cout, int Cin, void* stream);

@@ -31,16 +31,19 @@ for cin, cout, hw in shapes:
     flops = 2.0 * B * hw * hw * cin * cout * 9
     wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
     L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
+    g1, g0 = torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda')
     with torch.no_grad():
-        xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True)
-    x6 = ops.mx_plane_of(xrec)     # round 5: the records' MX-FP6 plane (None when the library option c8_mx is 0)
-    # variant '2' = the w4 kernel with the correction product on MX-FP6 operands (record input only)
+        xrec = ops.group_norm_silu(x, g1, g0, 32, 1e-6, True, True)                  # format 1: f16 | e5m2 halves
+        xmx = ops.group_norm_silu(x, g1, g0, 32, 1e-6, True, True, cout=cout)        # format 2 where the layer takes it
+    have_mx = ops.packed_format(xmx) == 2
+    # variant '2' = the w4 kernel on MX operand records: correction product on block-scaled FP6 operands (round 5)
+    xin = lambda v: (xmx, 2) if v == '2' else (xrec, 1)
     cases = {
-        'fwd rec+gn+res': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xrec), L.ptr(x6) if v == '2' else None, L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, None, L.stream()),
-        'fwd rec+gn    ': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xrec), L.ptr(x6) if v == '2' else None, L.ptr(wp), L.ptr(bias), None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, None, L.stream()),
+        'fwd rec+gn+res': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xin(v)[0]), None, L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, xin(v)[1], L.ptr(gns), 32, None, L.stream()),
+        'fwd rec+gn    ': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xin(v)[0]), None, L.ptr(wp), L.ptr(bias), None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, xin(v)[1], L.ptr(gns), 32, None, L.stream()),
         'dgrad fp32+amax': lambda v: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()),
     }
-    variants = '012' if x6 is not None else '01'
+    variants = '012' if have_mx else '01'
     best = {(k, v): 1e9 for k in cases for v in variants}
     for rnd in range(3):
         for k, f in cases.items():
