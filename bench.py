@@ -254,21 +254,24 @@ def clock_probe(device, ms=40.0):
 Q_GN_STEP_PER_IMG = 3 * 1.405e9
 
 
-def ceiling(conv_flops_step, wgrad_flops_step, batch, ips, units=2.0, clock_ghz=1.77):
+def ceiling(conv_flops_step, wgrad_flops_step, batch, ips, units=2.0, clock_ghz=1.77, units_wgrad=None):
     """How far the north_star's 40 % of the HBM-roofline rate is, from this line alone.
     matrix-core floor = algorithmic 3x3 flops of the step (forward + data gradient + weight gradient, as timed above)
-    x MFMA units per product (f16c8: 2) / dense peak at the clock the chip HOLDS under this load;
+    x MFMA units per product (f16c8: 2 in the data gradient and on fp32 inputs, 1.64 in the MX-FP6 forward of the
+    operand-record layers, 1 in the f16 weight gradients) / dense peak at the clock the chip HOLDS under this load;
     HBM floor = the passes no matrix kernel can hide at the HBM peak: GroupNorm (forward apply, backward reduce +
     apply: SURVEY's 3 x 1.405 GB/img) and optimiser / clip / weight traffic (4.8 GB/step);
     1x1 / attention GEMMs, losses, the hyper-network and launch gaps are NOT in the floor (they are ~10 ms today)."""
-    flops = conv_flops_step + wgrad_flops_step
+    units_wgrad = units if units_wgrad is None else units_wgrad
+    work = conv_flops_step * units + wgrad_flops_step * units_wgrad      # flops x units
     peak_hold = PEAK_BF16_MFMA * clock_ghz / MAX_CLOCK_GHZ
-    t_mfma_hold = flops * units / peak_hold
-    t_mfma_max = flops * units / PEAK_BF16_MFMA
+    t_mfma_hold = work / peak_hold
+    t_mfma_max = work / PEAK_BF16_MFMA
     t_hbm = (Q_GN_STEP_PER_IMG * batch + Q_STEP_FIXED) / PEAK_HBM
     r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / batch)
     out = {
-        'mfma_units_per_product': units, 'clock_under_load_ghz': round(clock_ghz, 3),
+        'mfma_units_per_product': {'forward_and_data_gradient': round(units, 3), 'weight_gradient': round(units_wgrad, 3)},
+        'clock_under_load_ghz': round(clock_ghz, 3),
         'clock_source': 'eovae_clock_probe in this run (s_memtime / s_memrealtime around an f16-MFMA loop on every CU, right behind the timed region)',
         'matrix_floor_ms_at_held_clock': round(t_mfma_hold * 1e3, 2), 'matrix_floor_ms_at_2.4ghz': round(t_mfma_max * 1e3, 2),
         'hbm_floor_ms_unfused_passes': round(t_hbm * 1e3, 2),
@@ -278,8 +281,9 @@ def ceiling(conv_flops_step, wgrad_flops_step, batch, ips, units=2.0, clock_ghz=
         'target_hbm_roofline_frac': 0.40, 'target_images_per_sec': round(0.40 * r_hbm, 1),
         'achieved_frac_of_ceiling': round(ips / (batch / (t_mfma_hold + t_hbm)), 4),
         'note': 'at 100 % MFMA-busy and the clock the chip holds, plus the GroupNorm / optimiser passes at the HBM peak; the '
-                'target needs ~51 ms/step, i.e. this arithmetic (2 units per product) leaves it out of reach unless the '
-                'held clock rises or GroupNorm traffic is fused away',
+                'target needs ~51 ms/step: ' + ('inside this ceiling' if (t_mfma_hold + t_hbm) * 1e3 < 51.0 else
+                                                'beyond this ceiling, i.e. out of reach for this arithmetic at this clock')
+                + ' (1x1 / attention GEMMs, losses, the hyper-networks and launch gaps are not in it)',
     }
     return out
 
@@ -448,13 +452,20 @@ def main():
         elif prec == 'f16c8':
             peak, dtype = PEAK_BF16_MFMA, 'f16c8'
             kname = ('conv3x3_f16c8_w4_kernel (plain 3x3 conv fwd + data-grad: one wave per SIMD, 4x4 register blocking, '
-                     'f16 product + one fp8 correction product)' if dom else
+                     'f16 product + one correction product: block-scaled MX-FP6 on operand-record inputs, fp8 on fp32 inputs)'
+                     if dom else
                      'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)')
-            path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) on v_mfma_f32_32x32x16_f16 + ONE K-concatenated '
-                    'block-scaled fp8 product [x_lo|x_hi].[w_hi|w_lo] on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 '
-                    'accumulate (~1e-5 per product; 2 MFMA units per algorithmic product => frac <= 1/2), forward, data '
-                    'gradient and weight gradient; GroupNorm hands activations over as f16c8 operand records; 1x1 '
-                    'convolutions and attention stay split-bf16 (3 units)')
+            lib_ = ops.L.load()
+            mx_on, wcorr = lib_.eovae_get_option(b'c8_mx') != 0, lib_.eovae_get_option(b'c8_wgrad_corr') != 0
+            path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) on v_mfma_f32_32x32x16_f16 + ONE K-concatenated block-scaled '
+                    'correction product [x_lo|x_hi].[w_hi|w_lo] on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate (~1e-5 per '
+                    'product): '
+                    + ('MX-FP6 (e2m3, per-32-channel E8M0 scales; 1.64 MFMA units per product) in the forward of the layers '
+                       'GroupNorm feeds with MX operand records, ' if mx_on else '')
+                    + 'fp8 (e5m2 / e4m3; 2 units) in the data gradient and on fp32 inputs; weight gradients: '
+                    + ('f16 product + fp8 correction (2 units)' if wcorr else
+                       'f16(dY)*f16(X) alone (1 unit: a leaf of the computation, its rounding does not compound)')
+                    + '; 1x1 convolutions and attention stay split-bf16 (3 units)')
         else:
             peak = PEAK_BF16_MFMA
             kname = 'conv3x3_bf16_kernel (3x3 conv fwd + data-grad, split-bf16 operands)'
@@ -489,8 +500,11 @@ def main():
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
             'roofline_conv8': conv8_roofline(timer, peak, elapsed) if dom else None,
             'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),
+            # f16c8: forward = half of the conv flops, ~0.86 of it (the plain layers behind a GroupNorm) on the MX-FP6 form
             'ceiling': ceiling(timer.totals()[1] / args.steps, wtimer.totals()[1] / args.steps, args.batch, ips / world,
-                               2.0 if prec == 'f16c8' else (3.0 if prec == 'bf16x3' else (16.0 if prec == 'f32' else 1.0)), clock_ghz)
+                               ((2.0 - 0.5 * 0.86 * (2.0 - 1.64) if mx_on else 2.0) if prec == 'f16c8' else
+                                (3.0 if prec == 'bf16x3' else (16.0 if prec == 'f32' else 1.0))), clock_ghz,
+                               (2.0 if wcorr else 1.0) if prec == 'f16c8' else None)
             if args.workload != 'cfg5' else None,
             'clock_state': {'probe_ghz': round(clock_ghz, 3), 'probe_loop_ms': round(clock_ms, 1),
                             'state': 'high' if clock_ghz >= CLOCK_STATE_HIGH_GHZ else 'common',
