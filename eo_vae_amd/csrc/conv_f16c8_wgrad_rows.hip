@@ -112,6 +112,11 @@ __device__ __forceinline__ void mfma16(f32x16& c, const f16x8& a, const f16x8& b
   if (EOVAE_ROWS_ABL & 8) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return; }
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// 16 x 16 x 32 form (Q16): a quarter of the output tile, the whole 32-pixel row as K
+__device__ __forceinline__ void mfma16q(f32x4& c, const f16x8& a, const f16x8& b) {
+  if (EOVAE_ROWS_ABL & 8) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return; }
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void mfma8(f32x16& c, const i32x8& a, const i32x8& b, int sa, int sb) {
   if (EOVAE_ROWS_ABL & 8) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return; }
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:1 blgp:1"
@@ -149,8 +154,16 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
 // layers; tools/scheme_probe_grad.py / profiles/r05_scheme_probe_wgrad.log (emulation) and the full-size pins of
 // tests/test_gpu_model.py hold the same gradient bars as before.  true = the r4 arithmetic (library option
 // c8_wgrad_corr = 1).
-template <int SP, bool CORR>
+// Q16 (round 5, plain f16-only form): the same products on v_mfma_f32_16x16x32_f16 -- a wave's 32 co x 32 ci tile of a tap is
+// four 16 x 16 accumulators, one MFMA takes the whole 32-pixel row as its K (36 MFMAs of 16 cycles per stage instead of 18 of
+// 32).  Same LDS images, same number of fragment reads, same registers; what changes is the clock the chip holds under the
+// loop (MI355X_MICROARCH.md 'DVFS give-back' (7); tools/probe_mfma_shape.hip: 1.15 x the FLOP/s at equal cycles).
+// Fragment maps: A (dY) lane (li, g) = row 16 half + li, pixels 8 g .. 8 g + 7: one ds_read_b128; B (X) lane (li, g) = channel
+// 16 nh + li, pixels 8 g + kx ..: the two transposing reads of the 32 x 32 form with (channel half, k half) = (nh, g) instead
+// of (g & 1, g >> 1); D lane (li, g) = ci 16 nh + li, co 16 half + 4 g + q.
+template <int SP, bool CORR, bool Q16 = false>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) {
+  static_assert(!Q16 || (SP == 0 && !CORR), "Q16: the plain f16-only form");
   __shared__ __attribute__((aligned(16))) unsigned char dys[SP ? 4 * DYSLOT : NRING * DYSLOT];   // SP: 2 slots x 2 pixel planes
   // FOUR arrays for the LDS-DMA targets (X row s + 3 is requested in stage s; row s + 1 is already read at the end of
   // stage s): with one array and a computed slot offset the compiler cannot tell a DMA write from the fragment reads of
@@ -362,12 +375,25 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   // block 0 = xh' (second 8 bytes of the pixel's 16), block 1 = xl'
   const int b8off = X16 + cih * X8T + x8off(2 * (g & 1) + (li & 1)) + (li >> 1) * 16 + ((g >> 1) ? 0 : 8) + pxw * 16;
 
+  // Q16: A row li of co-half `half` (+ half * 16 P16), pixels 8 g ..; B as b16off with the k-group g and the channel half as an
+  // immediate (+ nh * 2 XP16)
+  const int a16q = (32 * ct + li) * P16 + 16 * g;
+  const int b16q = (4 * cih + ((li & 3) >> 1)) * XP16 + (8 * g + (li >> 2)) * 16 + (li & 1) * 8;
+
   constexpr int NT = SP ? 8 : 9;   // SP: acc[4 ci-tile + 2 a + b]
-  f32x16 acc[NT];
+  f32x16 acc[Q16 ? 1 : NT];
+  f32x4 acc4[Q16 ? 9 : 1][2][2];   // Q16: [tap][co half][ci half]
+  if constexpr (Q16) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+      for (int q = 0; q < 16; ++q) acc4[t][(q >> 3) & 1][(q >> 2) & 1][q & 3] = 0.f;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  }
   f16x8 A16[NRING][2];
   i32x8 A8[NRING];
 #pragma unroll
@@ -415,6 +441,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   f16x8 nb0 = A16[0][0], nb1 = A16[0][0];   // !CORR: the B fragments of the next sub-step, read one sub-step ahead
   if constexpr (CORR) {
     b8 = rtr8(xs0 + b8off);
+  } else if constexpr (Q16) {
+    nb0 = rtr16(xs0 + b16q, xs0 + b16q + 4 * 16);
+    nb1 = rtr16(xs0 + b16q + 2 * XP16, xs0 + b16q + 2 * XP16 + 4 * 16);
   } else {
     nb0 = rtr16(xs0 + b16off, xs0 + b16off + 4 * 16);
     nb1 = rtr16(xs0 + b16off + 16 * 16, xs0 + b16off + 20 * 16);
@@ -437,13 +466,65 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     // fragments are requested first thing and are needed by the third MFMA.  The requests of dY row s + 2 and X row
     // s + 3 and the cursor step ride between the MFMAs of kx = 0, the conversion of dY row s + 1 (requested a stage ago)
     // between the triples of kx = 1.
+    constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3;   // ring positions of ky = 1, 2 (ky = 0: K)
+    if constexpr (Q16) {
+      // 36 MFMAs of 16 cycles, in the order of the 32 x 32 form: per kx the two OLD rows first (eight MFMAs on operands that
+      // are in registers when the barrier opens), then the new row's four; the requests ride between the first MFMAs of
+      // kx = KREQ, the conversion of dY row s + 1 around the B reads of kx = KCNV.
+      A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16q));
+      A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16q + 16 * P16));
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f16x8 b0 = nb0, b1 = nb1;
+        if (kx == KCNV) {
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + NDY + NX) : "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3)
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16q(acc4[3 + kx][0][0], A16[R1][0], b0);
+        if (kx == KREQ) {
+          __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
+          if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
+        }
+        mfma16q(acc4[6 + kx][0][0], A16[R2][0], b0);
+        mfma16q(acc4[3 + kx][0][1], A16[R1][0], b1);
+        if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) {
+          request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
+          save_dy();
+        }
+        mfma16q(acc4[6 + kx][0][1], A16[R2][0], b1);
+        mfma16q(acc4[3 + kx][1][0], A16[R1][1], b0);
+        if (kx == KREQ && !(EOVAE_ROWS_ABL & 2)) step();
+        mfma16q(acc4[6 + kx][1][0], A16[R2][1], b0);
+        mfma16q(acc4[3 + kx][1][1], A16[R1][1], b1);
+        mfma16q(acc4[6 + kx][1][1], A16[R2][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kx < 2) {
+          nb0 = rtr16(xsl + b16q + (kx + 1) * 16, xsl + b16q + (kx + 5) * 16);
+          nb1 = rtr16(xsl + b16q + 2 * XP16 + (kx + 1) * 16, xsl + b16q + 2 * XP16 + (kx + 5) * 16);
+        } else {   // the next stage's first B fragments
+          const unsigned char* xn = xslot_of(std::integral_constant<int, (Q + 1) % 4>{});
+          nb0 = rtr16(xn + b16q, xn + b16q + 4 * 16);
+          nb1 = rtr16(xn + b16q + 2 * XP16, xn + b16q + 2 * XP16 + 4 * 16);
+        }
+        if (kx == KCNV && !(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16q(acc4[kx][0][0], A16[K][0], b0);
+        mfma16q(acc4[kx][0][1], A16[K][0], b1);
+        mfma16q(acc4[kx][1][0], A16[K][1], b0);
+        mfma16q(acc4[kx][1][1], A16[K][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + NX) : "memory");   // X(s + 2) has landed: only this stage's requests may be outstanding
+      if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      return;
+    }
     if constexpr (CORR) {
       const i32x4 l = *reinterpret_cast<const i32x4*>(dsl + a8off), u = *reinterpret_cast<const i32x4*>(dsl + a8off + 16);
       A8[K] = (i32x8)__builtin_shufflevector(l, u, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off));
     A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16off + 32));
-    constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3;   // ring positions of ky = 1, 2 (ky = 0: K)
     if constexpr (!CORR) {
       // 18 f16 MFMAs.  Per kx: the two OLD rows (register ring) first -- four MFMAs on operands that are in registers when
       // the barrier opens (their B fragments were read one sub-step ahead) -- then the new row, whose A fragments were
@@ -685,6 +766,19 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   }
   // this block's partial tile [tap][128 co][64 ci], folded in a fixed order by wgrad_fold_kernel
   // (SP: eight tiles per block [px][2 a + b][128 co][64 ci]; the wave holds [ci-tile][2 a + b] of its px)
+  if constexpr (Q16) {   // lane (li, g): ci = 32 cih + 16 nh + li, co = 32 ct + 16 half + 4 g + q
+    float* pq = a.part + ((size_t)slab * a.split + ysub) * 9 * (128 * 64) + (32 * ct + 4 * g) * 64 + 32 * cih + li;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pq[(size_t)t * (128 * 64) + (16 * hf + q) * 64 + 16 * nh] = acc4[t][hf][nh][q] * dyinv;
+    return;
+  }
   float* pt = a.part + (((size_t)slab * a.split + ysub) * (SP ? 8 : 9) + (SP ? 4 * pxw : 0)) * (128 * 64) + cih * 32 + r;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -833,6 +927,8 @@ void eovae_c8_wgrad_rows_launch(WgCArgs& a, hipStream_t st) {
   a.xcd_remap = (a.ncib * a.ncob_ > 1 && a.split % 8 == 0) ? 1 : 0;
   if (eovae_opt(EOVAE_OPT_C8_WGRAD_CORR))
     hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<0, true>), dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
+  else if (eovae_opt(EOVAE_OPT_C8_Q16))
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<0, false, true>), dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
   else
     hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<0, false>), dim3(a.ncib * a.ncob_ * a.split), dim3(512), 0, st, a);
 }

@@ -21,6 +21,7 @@ enum {
   EOVAE_OPT_C8_PACK_GATHER,   // per-layer weight packs by the rounds-2/3 per-element gather kernel (0; tests: reference of the LDS-staged pack)
   EOVAE_OPT_C8_MX,            // correction product on block-scaled FP6 operands where the kernel and its inputs allow it (1); 0: fp8 everywhere
   EOVAE_OPT_C8_WGRAD_CORR,    // row-streaming weight gradients WITH the fp8 correction product (the r4 arithmetic): 1; 0 (default): f16 x f16 alone
+  EOVAE_OPT_C8_Q16,           // 16 x 16 MFMA shape in the kernels that have that form (1): the chip holds a higher clock on it; 0: 32 x 32
   EOVAE_OPT_COUNT
 };
 int eovae_opt(int id);

@@ -106,6 +106,32 @@ def test_rows_weight_gradient(n, cin, cout, h, w, corr):
         ops.CONV_PRECISION = old
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w', SHAPES)
+def test_rows_mfma_shapes_agree(n, cin, cout, h, w, corr):
+    """Library option c8_q16: the f16-only kernel on v_mfma_f32_16x16x32_f16 (default) and on v_mfma_f32_32x32x16_f16 multiply
+    the same operands; only the order inside the fp32 sums differs."""
+    if corr:
+        pytest.skip('the correction-product form has one MFMA shape')
+    from eo_vae_amd import lib as L
+    lib = L.load()
+    ops, x, wt, b, gy, g, be = _case(n, cin, cout, h, w)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = lib.eovae_get_option(b'c8_q16')
+    try:
+        assert keep == 1
+        got = {}
+        for v in (1, 0):
+            L.check(lib.eovae_set_option(b'c8_q16', v), 'set_option')
+            got[v] = _run(ops, x, wt, b, gy, g, be)
+        e = rel_err(got[1][0], got[0][0])
+        print(f'16x16x32 vs 32x32x16: {e:.2e}')
+        assert e < 2e-6 and float(got[1][0].abs().max()) > 0
+        assert rel_err(got[1][1], got[0][1]) < 2e-6    # (the bias gradient does not pass through the MFMAs; float atomics)
+    finally:
+        lib.eovae_set_option(b'c8_q16', keep)
+        ops.CONV_PRECISION = old
+
+
 def test_rows_kernel_is_the_default_and_switchable():
     from eo_vae_amd import lib as L
     lib = L.load()

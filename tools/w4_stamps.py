@@ -1,13 +1,14 @@
 """Per-tile timeline of the one-wave-per-SIMD convolution kernel from a diagnostic build
 (SRC=conv_f16c8_w4 tools/build_variant.sh w4stamp -DEOVAE_W4_STAMP=1): cycles of the phase sequence, the epilogue,
 the accumulator reset and the GroupNorm flush of each tile, and the shader clock held.
-    EOVAE_LIB=eo_vae_amd/build/exp/lib_w4stamp.so python tools/w4_stamps.py [cin cout hw [res]]"""
+    EOVAE_LIB=eo_vae_amd/build/exp/lib_w4stamp.so python tools/w4_stamps.py [cin cout hw [res] [mx]]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from eo_vae_amd import ops, lib as L
 cin, cout, hw = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (128, 128, 256)
-use_res = len(sys.argv) >= 5 and sys.argv[4] == 'res'
+use_res = 'res' in sys.argv[4:]
+use_mx = 'mx' in sys.argv[4:]     # MX operand records (format 2): the FP6 correction product
 os.environ['EOVAE_C8_W4'] = '1'
 ops.CONV_PRECISION = 'f16c8'
 lib = L.load()
@@ -17,11 +18,15 @@ w = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
 y = torch.empty(B, cout, hw, hw, device='cuda')
 res = torch.randn_like(y) if use_res else None
 gns = torch.zeros(B, 32, 2, dtype=torch.float64, device='cuda')
-xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True).detach()
+xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True,
+                           cout=cout if use_mx else None)
+fmt = ops.packed_format(xrec)
+assert fmt == (2 if use_mx else 1), fmt
 wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
 L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
 for _ in range(30):   # warm: clocks settle under load
-    L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(xrec), L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 1, L.ptr(gns), 32, L.stream()), 'fwd')
+    L.check(lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xrec), None, L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, fmt,
+                                           L.ptr(gns), 32, None, L.stream()), 'fwd')
 torch.cuda.synchronize()
 NPT, MAXREC, NBLK = 7, 32, 8
 buf = np.zeros(NBLK * 4 * MAXREC * NPT, dtype=np.uint64)

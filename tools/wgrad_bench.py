@@ -1,4 +1,6 @@
-"""A/B of the plain f16c8 weight-gradient kernels at the real layer shapes (B=16), interleaved rounds in one process,
+"""WGRAD_BENCH_Q16=1: instead, the row-streaming kernel's two MFMA shapes (library option c8_q16 = 0: 32x32x16, 1: 16x16x32),
+alternating, plain layers only.
+A/B of the plain f16c8 weight-gradient kernels at the real layer shapes (B=16), interleaved rounds in one process,
 through the product entry (eovae_conv3x3_f16c8_wgrad_dw: partial tiles + fold, record input):
 option c8_wgrad_rows = 0 -> wgrad3x3_f16c8_kernel (tile kernel), 1 -> conv_f16c8_wgrad_rows.hip (row streaming)."""
 import sys, os
@@ -20,6 +22,30 @@ if len(sys.argv) > 1:
 B = 16
 lib = L.load()
 ops.CONV_PRECISION = 'f16c8'
+if os.environ.get('WGRAD_BENCH_Q16') == '1':
+    for cin, cout, hw in shapes:
+        x = torch.randn(B, cin, hw, hw, device='cuda')
+        dy = torch.randn(B, cout, hw, hw, device='cuda') * 1e-4
+        dw = torch.zeros(cout, cin, 3, 3, device='cuda')
+        db = torch.zeros(cout, device='cuda')
+        amax = ops.absmax_bits(dy)
+        flops = 2.0 * B * hw * hw * cin * cout * 9
+        xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, device='cuda'), 32, 1e-6, True, True, cout=cout)
+        fmt = ops.packed_format(xrec)
+        ws = torch.empty(lib.eovae_conv3x3_f16c8_wgrad_dw_workspace(cin, cout) // 4, device='cuda')
+        run = lambda: lib.eovae_conv3x3_f16c8_wgrad_dw(L.ptr(xrec), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(amax), None, B, cin, hw, hw,
+                                                       cout, hw, hw, fmt, L.ptr(ws), L.stream())
+        best, res = {0: 1e9, 1: 1e9}, {}
+        for rnd in range(4):
+            for v in (0, 1):
+                lib.eovae_set_option(b'c8_q16', v)
+                best[v] = min(best[v], timeit(run, 20))
+                res[v] = dw.clone()
+        err = ((res[1] - res[0]).abs().max() / res[0].abs().max()).item()
+        t0, t1 = best[0], best[1]
+        print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 rows wgrad (records format {fmt}, incl. fold): 32x32x16 {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | '
+              f'16x16x32 {t1:7.3f} ms {flops/t1/1e9:6.1f} TF | x{t0/t1:.3f} | difference {err:.1e}', flush=True)
+    sys.exit(0)
 for cin, cout, hw in shapes:
     x = torch.randn(B, cin, hw, hw, device='cuda')
     dy = torch.randn(B, cout, hw, hw, device='cuda') * 1e-4
