@@ -1,0 +1,492 @@
+// 3x3 stride-1 convolution on MX operand records -- ONE WAVE PER SIMD, 16 x 16 MFMAs, every byte fed by LDS-DMA (round 5).
+//
+// Same arithmetic, operand records, weight packs and C-ABI entry as conv_f16c8_w4.hip's MX instantiation
+// (x*w ~= f16(x)*f16(w) + one block-scaled e2m3 correction product, conv_f16c8_common.h); same block tile (128 co x 16 rows
+// x 32 px, four waves of 128 co x 4 rows) and persistent walk.  What changes:
+//
+//   MFMA shape     v_mfma_f32_16x16x32_f16 / v_mfma_scale_f32_16x16x128_f8f6f4 instead of the 32 x 32 forms: a wave's tile is
+//                  8 x 8 accumulators of 16 x 16 (256 AGPRs, as before).  Same flops per cycle, same LDS bytes per flop -- but
+//                  the chip holds a higher clock under a loop of the small shape (MI355X_MICROARCH.md 'DVFS give-back' (7);
+//                  tools/probe_mfma_shape.hip: 1.85 against 1.66 GHz at equal cycles on this kernel's operand mix;
+//                  profiles/r05t_w4_q16_stamps.log: 1.90 against 1.63 GHz inside conv_f16c8_w4.hip's phase sequence).
+//   correction     the 16 x 16 x 128 form takes FOUR 32-element K blocks: [x_lo | x_hi] of tap t and of tap t + 1 against
+//                  [w_hi | w_lo] of the same two taps (lane group g = lane / 16 supplies block g: tap t + g / 2, part g % 2 --
+//                  its B address carries that tap's pixel shift).  Nine taps = four pairs + one tap whose second half is a
+//                  zero weight unit.  A 32-channel chunk is 9 f16 phases + 5 correction phases of 64 MFMAs each.
+//   feed           records need no conversion, so nothing passes through registers: the halo images (F plane -> f16 image,
+//                  S plane -> FP6 image) and the weight units go global -> LDS by buffer_load ... lds.  No staging registers,
+//                  no ds_write, no conversion VALU; a wave's instruction stream is MFMAs, fragment reads and a few DMA
+//                  requests per phase.  Out-of-image halo pixels are lane offsets beyond the descriptor's range (zeros).
+//   issue order    every MFMA and every fragment read is a volatile asm statement in program order; waits are counted by
+//                  hand (lgkmcnt: the reads are the wave's only LDS instructions; vmcnt: DMA requests per phase are
+//                  compile-time constants).  hipcc 7.2 cannot keep 64 four-register accumulators in place through the
+//                  builtins (it renames destinations and repairs the loop's back edge with hundreds of v_accvgpr moves),
+//                  and it does not schedule around inline-asm MFMAs.
+//
+// Phases of a chunk: p = 0..8 f16 product of tap p; p = 9..13 correction product of taps (2m, 2m + 1), m = p - 9.
+//   weights of phase p + 3 are requested in phase p into slot (P + 3) % 4 of a four-slot ring (P = running phase number);
+//   the FP6 image of the chunk is requested in phases 0..4 (first read: the B fragments of phase 9, requested in phase 8);
+//   the f16 image of the NEXT chunk in phases 8..11 (its last reader of this chunk is phase 8, whose fragments were
+//   requested in phase 7; first reader: phase 13, which requests phase 0's B fragments).
+//   End of phase p: s_waitcnt vmcnt(requests of phase p) -- everything older has landed -- then the workgroup barrier.
+//
+// Restrictions (conv_f16c8_w4.hip runs otherwise): those of that kernel, MX operand records, library option c8_q16.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_f16c8_common.h"
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+using lds_ptr = __attribute__((address_space(3))) void*;
+
+constexpr int QBM = 128, QXW = 34, QNPX = 18 * QXW, QNTASK = 10;
+constexpr int QPPL = 640 * 16;                 // one octet's / piece's plane of the halo images: 640 pixels (612 + DMA padding)
+constexpr int QIMG = 4 * QPPL;                 // 40,960
+constexpr int QOFF_XF = 0, QOFF_X6 = QIMG, QOFF_W = 2 * QIMG;
+constexpr int QWSLOT = 16384, QNWS = 4;        // weight ring: four phase slots of two 8 KB units
+constexpr int QLDS = QOFF_W + QNWS * QWSLOT;   // 147,456
+constexpr int QNPH = 14;                       // phases per chunk
+
+// requests of a phase: weight DMAs for phase p + 3 (two per 8 KB unit), halo DMAs
+__device__ __host__ constexpr int q_is_c(int p) { return ((p % QNPH) + QNPH) % QNPH >= 9; }
+__device__ __host__ constexpr int q_nw(int p) { return q_is_c(p + 3) ? 4 : 2; }
+__device__ __host__ constexpr int q_nh(int p) { return p <= 4 ? 2 : (p == 8 || p == 9) ? 3 : (p == 10 || p == 11) ? 2 : 0; }
+
+template <int OFF>
+__device__ __forceinline__ void rd128(i32x4& d, unsigned a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+}
+__device__ __forceinline__ void mfma_f(f32x4& c, const i32x4& a, const i32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_c(f32x4& c, const i32x6& a, const i32x6& b, int sa, int sb) {
+  // s_nop 1: the operands' last two dwords reach their six-register tuples through v_mov copies, and an MFMA may not read a
+  // register a VALU instruction wrote less than two wait states earlier -- a hazard hipcc covers for its own MFMAs only
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+               : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+#ifndef EOVAE_Q16_SAFE
+#define EOVAE_Q16_SAFE 0   // bisection: 1 every counted vmcnt wait becomes vmcnt(0), 2 every counted lgkmcnt wait lgkmcnt(0)
+#endif
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((EOVAE_Q16_SAFE & 2) ? 0 : N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EOVAE_Q16_SAFE & 1) ? 0 : (N < 63 ? N : 63)) : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) {
+  // the DMA targets / fragment sources; the GroupNorm cells live in an array of their own so that the compiler does not
+  // take their (plain) accesses for possible readers of a pending DMA and drain vmcnt(0) -- the epilogue's stores
+  // included -- in front of them
+  __shared__ __attribute__((aligned(16))) unsigned char smem[QLDS];
+  __shared__ float gcell[4 * 2 * QBM];   // [wave][sum | sumsq][channel of the block]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wrow = wave * 4;
+  const size_t in_plane = (size_t)a.Hin * a.Win;
+  const size_t out_plane = (size_t)a.Hout * a.Wout;
+
+  struct Tile { int cob, n, oy0, ox0; };
+  auto decode = [&](int b) {
+    Tile t;
+    if (a.xcd_remap) {  // the ncob blocks sharing one halo tile take consecutive slots of ONE XCD
+      const int xcd = b & 7, q = b >> 3;
+      t.cob = q % a.ncob;
+      b = (q / a.ncob) * 8 + xcd;
+    } else {
+      t.cob = b % a.ncob;
+      b /= a.ncob;
+    }
+    const int tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    t.n = b / a.tiles_y;
+    t.oy0 = ty * 16;
+    t.ox0 = tx * 32;
+    return t;
+  };
+
+  float xinv = 1.f;   // records of a range-guarded input (none today): undone with the result, as conv_f16c8_w4.hip
+  if (a.xamax) {
+    const unsigned bits = *a.xamax;
+    if (bits) xinv = pow2f(expo_of_bits(bits) - 13);
+  }
+
+  // ---------------------------------------------------------------- halo requests (wave = channel octet / FP6 piece)
+  // task k of a wave: pixels 64 k + lane of the 18 x 34 halo; the lane's offset in its plane, or out of range (zeros)
+  const unsigned OOR = 0x80000000u;
+  unsigned xoff[QNTASK];
+  auto setup_x = [&](const Tile& t) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // keeps the per-task index math out of the registers that live across the chunk loop
+#pragma unroll
+    for (int k = 0; k < QNTASK; ++k) {
+      const int pix = ln + 64 * k;
+      const int rr = (pix * 241) >> 13, cc = pix - QXW * rr;   // pix / 34, exact for pix < 640
+      const int vy = t.oy0 + rr - 1, vx = t.ox0 + cc - 1;
+      const bool ok = (pix < QNPX) & ((unsigned)vy < (unsigned)a.Hin) & ((unsigned)vx < (unsigned)a.Win);
+      xoff[k] = ok ? (unsigned)(vy * a.Win + vx) * 16u : OOR;
+    }
+  };
+  const unsigned plane_bytes = (unsigned)(in_plane * 16);
+  auto srd_xf = [&](const Tile& t, int chunk) __attribute__((always_inline)) {   // F plane [n][Cin / 8][pixel][16 B], octet 4 chunk + wave
+    const char* p = reinterpret_cast<const char*>(a.x) + (((size_t)t.n * (a.Cin / 8) + 4 * chunk + wave) * in_plane) * 16;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, plane_bytes, 0x00020000);
+  };
+  auto srd_x6 = [&](const Tile& t, int chunk) __attribute__((always_inline)) {   // S plane [n][Cin / 32][piece][pixel][16 B], piece = wave
+    const char* p = reinterpret_cast<const char*>(a.x6) + ((((size_t)t.n * (a.Cin / 32) + chunk) * 4 + wave) * in_plane) * 16;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, plane_bytes, 0x00020000);
+  };
+  unsigned char* const xf_dst = smem + QOFF_XF + wave * QPPL;
+  unsigned char* const x6_dst = smem + QOFF_X6 + wave * QPPL;
+  auto dma_x = [&](const __amdgpu_buffer_rsrc_t& srd, unsigned char* dst, int k) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr)(dst + k * 1024), 16, (int)xoff[k], 0, 0, 0);
+  };
+
+  // ---------------------------------------------------------------- weight requests: 8 KB units, two DMAs each
+  const size_t wbytes = (size_t)9 * a.nchunk * a.ncob * C8_WTILE;
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wp), 0, (unsigned)wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wp), 0, 0u, 0x00020000);
+  const int wvoff = tid * 16;
+  auto dma_unit = [&](const __amdgpu_buffer_rsrc_t& srd, unsigned soff, unsigned slotbyte) __attribute__((always_inline)) {
+    unsigned char* dst = smem + QOFF_W + slotbyte + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr)dst, 16, wvoff, (int)soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr)(dst + 4096), 16, wvoff, (int)(soff + 4096u), 0, 0);
+  };
+  // units of phase q (0..13) of chunk `chunk` of co-block `cob` into ring slot `slot`
+  auto request_w = [&](auto qc, int cob, int chunk, unsigned slot) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    const unsigned sb = slot * QWSLOT;
+    if constexpr (q < 9) {
+      dma_unit(wsrd, (unsigned)(((size_t)(q * a.nchunk + chunk) * a.ncob + cob) * C8_WTILE), sb);
+    } else {
+      constexpr int t0 = 2 * (q - 9);
+      dma_unit(wsrd, (unsigned)(((size_t)(t0 * a.nchunk + chunk) * a.ncob + cob) * C8_WTILE + C8_WOFF6), sb);
+      if constexpr (t0 + 1 < 9)
+        dma_unit(wsrd, (unsigned)(((size_t)((t0 + 1) * a.nchunk + chunk) * a.ncob + cob) * C8_WTILE + C8_WOFF6), sb + 8192);
+      else
+        dma_unit(zsrd, 0u, sb + 8192);   // the ninth tap has no partner: a unit of zeros (descriptor of zero records)
+    }
+  };
+
+  // ---------------------------------------------------------------- fragments
+  // lane (li, g) of a 16 x 16 MFMA: A row / B column li, K block g.
+  //   f16:  K block g = channel octet g of the chunk.   A: weight unit [octet][row][16 B]; B: f16 image [octet][pixel][16 B]
+  //   FP6:  K block g = (tap t + g / 2, part g % 2).     A: units of the two taps [tap][part][piece][row][16 B]; B: FP6 image
+  //         pieces 2 (g % 2), 2 (g % 2) + 1 at the pixel shifted by THAT tap
+  const unsigned a_f = (unsigned)(QOFF_W + g * 2048 + li * 16);
+  const unsigned a_c = (unsigned)(QOFF_W + (g >> 1) * 8192 + (g & 1) * 4096 + li * 16);
+  const unsigned b_f = (unsigned)(QOFF_XF + g * QPPL + (wrow * QXW + li) * 16);
+  const unsigned b_c = (unsigned)(QOFF_X6 + 2 * (g & 1) * QPPL + (wrow * QXW + li) * 16);
+  const unsigned gsel = (unsigned)(g >> 1);
+
+  f32x4 acc[8][8];   // [co tile of 16][pixel tile: row 0..3 x half 0..1]
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
+  };
+  // fragment registers: A streamed by co-tile pairs [pair parity][tile][lo | hi], B held per phase [phase parity][tile][lo | hi]
+  // (f16 fragments use [..][0] only)
+  i32x4 Ar[2][2][2], Br[2][8][2];
+
+  // A fragments of co-tile pair c2 of a phase whose ring slot starts at byte `sb` (runtime), into Ar[c2 & 1]
+  auto read_a = [&](auto isc, auto c2c, unsigned sb) __attribute__((always_inline)) {
+    constexpr bool ISC = decltype(isc)::value;
+    constexpr int c2 = decltype(c2c)::value;
+    const unsigned base = (ISC ? a_c : a_f) + sb;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if constexpr (ISC) {
+        if (t == 0) { rd128<(2 * c2) * 256>(Ar[c2 & 1][0][0], base); rd128<(2 * c2) * 256 + 2048>(Ar[c2 & 1][0][1], base); }
+        else { rd128<(2 * c2 + 1) * 256>(Ar[c2 & 1][1][0], base); rd128<(2 * c2 + 1) * 256 + 2048>(Ar[c2 & 1][1][1], base); }
+      } else {
+        if (t == 0) rd128<(2 * c2) * 256>(Ar[c2 & 1][0][0], base);
+        else rd128<(2 * c2 + 1) * 256>(Ar[c2 & 1][1][0], base);
+      }
+    }
+  };
+  // B fragment of pixel tile j (row j >> 1, half j & 1) of phase q into Br[q & 1][j]
+  auto read_b = [&](auto qc, auto jc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, j = decltype(jc)::value, jr = j >> 1, hx = j & 1;
+    if constexpr (q < 9) {
+      constexpr int ky = q / 3, kx = q - 3 * ky;
+      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16>(Br[q & 1][j][0], b_f);
+    } else {
+      constexpr int t0 = 2 * (q - 9), ky = t0 / 3, kx = t0 - 3 * ky;
+      constexpr int t1 = t0 + 1 < 9 ? t0 + 1 : t0, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
+      constexpr int delta = ((ky1 - ky) * QXW + (kx1 - kx)) * 16;   // the second tap's pixel shift against the first's
+      const unsigned base = b_c + gsel * (unsigned)delta;
+      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16>(Br[q & 1][j][0], base);
+      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16 + QPPL>(Br[q & 1][j][1], base);
+    }
+  };
+  // MFMA (co tile i, pixel tile j) of phase q
+  auto mma = [&](auto qc, auto ic, auto jc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, i = decltype(ic)::value, j = decltype(jc)::value;
+    constexpr int pr = (i >> 1) & 1, t = i & 1;
+    if constexpr (q < 9) {
+      mfma_f(acc[i][j], Ar[pr][t][0], Br[q & 1][j][0]);
+    } else {
+      // a fragment = 24 data bytes + scale dword in two adjacent 16-byte reads: the operand is the first six registers of
+      // the eight, the scale the seventh
+      const i32x8 a8 = __builtin_shufflevector(Ar[pr][t][0], Ar[pr][t][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const i32x8 b8 = __builtin_shufflevector(Br[q & 1][j][0], Br[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const i32x6 a6 = __builtin_shufflevector(a8, a8, 0, 1, 2, 3, 4, 5), b6 = __builtin_shufflevector(b8, b8, 0, 1, 2, 3, 4, 5);
+      mfma_c(acc[i][j], a6, b6, a8[6], b8[6]);
+    }
+  };
+
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  // The fragment reads are asm statements: to the compiler their results exist as soon as the statement is passed, and it
+  // may schedule a consumer of its own (the v_mov copies that build the FP6 operands' six-register tuples) in front of the
+  // hand-placed s_waitcnt -- i.e. copy registers the LDS has not written yet.  Behind every wait the registers it covers
+  // are therefore passed through an empty asm statement: their consumers depend on THAT.
+  auto landed_a = [&](int pr) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(Ar[pr][t][u]));
+  };
+  auto landed_b = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(Br[par][j][u]));
+  };
+
+  // ---------------------------------------------------------------- GroupNorm partial sums
+  auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {
+    const int v = tid >> 7, c = tid & 127;
+    float t = (gcell[(0 * 2 + v) * QBM + c] + gcell[(1 * 2 + v) * QBM + c]) + (gcell[(2 * 2 + v) * QBM + c] + gcell[(3 * 2 + v) * QBM + c]);
+    const int cpg = 1 << a.gn_shift;   // 4..64 channels per group (eligibility): inside one wave's 64 channels
+    for (int s = 1; s < cpg && s < 64; s <<= 1) t += __shfl_xor(t, s, 64);
+    if ((c & (cpg - 1)) == 0) atomicAdd(a.gn_sums + ((size_t)tn * a.gn_groups + ((tcb + c) >> a.gn_shift)) * 2 + v, (double)t);
+  };
+
+  // ---------------------------------------------------------------- epilogue
+  // acc[i][j][q]: channel 16 i + 4 g + q, pixel (row j >> 1, column 16 (j & 1) + li).  The 4 channels x 4 pixels of a lane
+  // quad are transposed inside the quad (DPP), so that lane 4 pq + m owns channel 4 g + m at pixels 4 pq .. 4 pq + 3 and
+  // every load / store moves 16 bytes per lane (conv_f16c8_w4.hip).
+  auto quad_transpose = [&](float (&v)[4], bool e0, bool e1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {   // lane bit 0 <-> register bit 0
+      const float send = e0 ? v[c] : v[c + 1];
+      const float rcv = dpp_quad<0xB1>(send);
+      v[c] = e0 ? rcv : v[c];
+      v[c + 1] = e0 ? v[c + 1] : rcv;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {      // lane bit 1 <-> register bit 1
+      const float send = e1 ? v[c] : v[c + 2];
+      const float rcv = dpp_quad<0x4E>(send);
+      v[c] = e1 ? rcv : v[c];
+      v[c + 2] = e1 ? v[c + 2] : rcv;
+    }
+  };
+  auto row_ror = [](float x, auto nc) __attribute__((always_inline)) {
+    constexpr int n = decltype(nc)::value;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + n, 0xf, 0xf, false));
+  };
+  auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
+    const int co_blk = t.cob * QBM;
+    const int m = lane & 3, pq = (lane >> 2) & 3;
+    const bool e0 = lane & 1, e1 = lane & 2;
+    // buffer addressing and no branch: an absent residual / bias is a descriptor of zero bytes (loads return 0)
+    const unsigned span = (unsigned)(QBM * out_plane * 4);
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+        a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane, 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, a.res ? span : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias ? a.bias + co_blk : a.y), 0, a.bias ? (unsigned)(QBM * 4) : 0u, 0x00020000);
+    const int lot = (int)(((size_t)(4 * g + m) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * pq) * 4);
+    const int lob = (4 * g + m) * 4;
+    const int tile16 = (int)(16 * out_plane * 4), rowb = a.Wout * 4;
+    float* const cell = gcell + wave * 2 * QBM;
+    // one co tile (16 channels x the wave's 4 rows x 32 pixels = 8 accumulators) at a time; the residual of the next co tile
+    // is requested while this one is written
+    f32x4 rv[2][8];
+    auto load_res = [&](f32x4 (&r)[8], int i) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64, 0));
+    };
+    load_res(rv[0], 0);
+    static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i + 1 < 8) load_res(rv[(i + 1) & 1], i + 1);
+      const float bias1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bsrd, lob, i * 64, 0));
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = acc[i][j][k];
+        quad_transpose(w, e0, e1);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[k] = __builtin_fmaf(w[k], xinv, bias1) + rv[i & 1][j][k];
+          sv += o[k];
+          qv = __builtin_fmaf(o[k], o[k], qv);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64, 0);
+      }
+      // statistics of the following GroupNorm: the four pixel quartets (lane bits 2, 3) of a channel summed by row rotations;
+      // written unconditionally, read by gn_flush() only when the caller asked for them
+      sv += row_ror(sv, std::integral_constant<int, 4>{}); qv += row_ror(qv, std::integral_constant<int, 4>{});
+      sv += row_ror(sv, std::integral_constant<int, 8>{}); qv += row_ror(qv, std::integral_constant<int, 8>{});
+      if (pq == 0) {
+        cell[16 * i + 4 * g + m] = sv;
+        cell[QBM + 16 * i + 4 * g + m] = qv;
+      }
+    });
+  };
+
+  // ---------------------------------------------------------------- prologue
+  int tile = blockIdx.x;
+  if (tile >= a.ntiles) return;
+  Tile cur = decode(tile);
+  setup_x(cur);
+  unsigned P = 0;   // running phase number (mod 4 = ring slot)
+  {
+    const __amdgpu_buffer_rsrc_t s0 = srd_xf(cur, 0);
+#pragma unroll
+    for (int k = 0; k < QNTASK; ++k) dma_x(s0, xf_dst, k);
+    request_w(std::integral_constant<int, 0>{}, cur.cob, 0, 0u);
+    request_w(std::integral_constant<int, 1>{}, cur.cob, 0, 1u);
+    request_w(std::integral_constant<int, 2>{}, cur.cob, 0, 2u);
+  }
+  zero_acc();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+  {
+    using Q0 = std::integral_constant<int, 0>;
+    read_a(std::false_type{}, Q0{}, 0u);
+    static_for<0, 8>([&](auto jc) __attribute__((always_inline)) { read_b(Q0{}, jc); });
+  }
+
+  // ---------------------------------------------------------------- main loop
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const bool has_next_tile = tile + (int)gridDim.x < a.ntiles;
+    Tile nxt = cur;
+    if (has_next_tile) nxt = decode(tile + gridDim.x);
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      const bool last_chunk = chunk + 1 == a.nchunk;
+      // the chunk whose f16 image and first weights are requested behind this one: the next chunk, the next tile's first, or
+      // (end of work) this chunk again -- re-requesting it writes the bytes that are already there
+      const bool wrap = last_chunk && has_next_tile;
+      const Tile& xt = wrap ? nxt : cur;
+      const int xchunk = last_chunk ? (has_next_tile ? 0 : chunk) : chunk + 1;
+      const __amdgpu_buffer_rsrc_t s6 = srd_x6(cur, chunk);
+      __amdgpu_buffer_rsrc_t sf = s6;   // (set at phase 7)
+      static_for<0, QNPH>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int pn = (p + 1) % QNPH;
+        constexpr bool ISC = p >= 9, NISC = pn >= 9;
+        using PN = std::integral_constant<int, pn>;
+        barrier();   // phase p's weights, the images it reads and its first fragments are there
+        landed_a(0);
+        landed_b(p & 1);
+        const unsigned sb = ((P + p) & 3u) * QWSLOT, sbn = ((P + p + 1) & 3u) * QWSLOT;
+        if constexpr (p == 7) {
+          if (wrap) setup_x(nxt);   // uniform; this chunk's FP6 image was requested in phases 0..4
+          sf = srd_xf(xt, xchunk);
+        }
+        static_for<0, 4>([&](auto c2c) __attribute__((always_inline)) {
+          constexpr int c2 = decltype(c2c)::value;
+          static_for<0, 16>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int mm = decltype(mc)::value;
+            constexpr int j = mm >> 1, i = 2 * c2 + (mm & 1);
+            mma(pc, std::integral_constant<int, i>{}, std::integral_constant<int, j>{});
+            // the phase's other work, one piece behind every MFMA pair
+            if constexpr (mm == 1) {
+              if constexpr (c2 == 0) {   // weights of phase p + 3
+                if constexpr (p + 3 < QNPH) request_w(std::integral_constant<int, p + 3>{}, cur.cob, chunk, (P + p + 3) & 3u);
+                else request_w(std::integral_constant<int, p + 3 - QNPH>{}, xt.cob, xchunk, (P + p + 3) & 3u);
+              }
+              if constexpr (c2 == 1) {   // halo requests of this phase
+                if constexpr (p <= 4) { dma_x(s6, x6_dst, 2 * p); dma_x(s6, x6_dst, 2 * p + 1); }
+                if constexpr (p == 8) { dma_x(sf, xf_dst, 0); dma_x(sf, xf_dst, 1); dma_x(sf, xf_dst, 2); }
+                if constexpr (p == 9) { dma_x(sf, xf_dst, 3); dma_x(sf, xf_dst, 4); dma_x(sf, xf_dst, 5); }
+                if constexpr (p == 10) { dma_x(sf, xf_dst, 6); dma_x(sf, xf_dst, 7); }
+                if constexpr (p == 11) { dma_x(sf, xf_dst, 8); dma_x(sf, xf_dst, 9); }
+              }
+            }
+            if constexpr (mm == 3) {     // A fragments of the next co-tile pair (of the next phase behind the last pair)
+              if constexpr (c2 < 3) read_a(std::integral_constant<bool, ISC>{}, std::integral_constant<int, c2 + 1>{}, sb);
+              else read_a(std::integral_constant<bool, NISC>{}, std::integral_constant<int, 0>{}, sbn);
+            }
+            if constexpr (mm == 7) read_b(PN{}, std::integral_constant<int, 2 * c2>{});
+            if constexpr (mm == 11) read_b(PN{}, std::integral_constant<int, 2 * c2 + 1>{});
+            if constexpr (mm == 15) {    // the next pair's A fragments have landed; the B reads behind them may be outstanding
+              if constexpr (c2 < 3) {
+                wait_lgkm<NISC ? 4 : 2>();
+                landed_a((c2 + 1) & 1);
+              }
+            }
+          });
+        });
+        // everything requested before this phase has landed (its own requests may be outstanding).  Behind a tile's last
+        // phase: all of it -- the epilogue's stores come next in the queue, and a counted wait behind them would wait
+        // for them too; the first phase of a tile therefore does not wait (its needs were met here).
+        if constexpr (p == QNPH - 1) {
+          if (last_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else wait_vm<q_nw(p) + q_nh(p)>();
+        } else if constexpr (p == 0) {
+          if (chunk != 0 || (EOVAE_Q16_SAFE & 1)) wait_vm<q_nw(p) + q_nh(p)>();
+        } else {
+          wait_vm<q_nw(p) + q_nh(p)>();
+        }
+      });
+      P += QNPH;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs' last results (hazards the compiler does not see)
+    epilogue_tile(cur);
+    zero_acc();
+    if (a.gn_sums) {   // uniform.  The cells are rewritten by the next epilogue, a whole tile later.
+      barrier();       // (raw: __syncthreads() carries a release fence = vmcnt(0), i.e. a wait for the epilogue's stores)
+      gn_flush(cur.n, cur.cob * QBM);
+    }
+    cur = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests behind the last chunk
+}
+
+}  // namespace
+
+bool eovae_c8_q16_eligible(const ConvCArgs& a) {
+  return eovae_opt(EOVAE_OPT_C8_Q16) != 0 && a.packed == 2 && a.x6 != nullptr && a.Hout % 16 == 0 && (!a.gn_sums || a.gn_shift <= 6) &&
+         (size_t)a.Hin * a.Win * 16 < (1ull << 31) && (size_t)9 * a.nchunk * a.ncob * C8_WTILE < (1ull << 32);
+}
+
+// a: prepared by eovae_c8_w4_launch (tiles, ntiles, xcd_remap)
+void eovae_c8_q16_launch(const ConvCArgs& a, int n_cu, hipStream_t st) {
+  const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(256);
+  hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel, grid, blk, 0, st, a);
+}

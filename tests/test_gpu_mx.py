@@ -24,13 +24,22 @@ def f16c8_mx():
     from eo_vae_amd import lib as L, ops
     lib = L.load()
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
-    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_mx', b'c8_wgrad_corr')}
+    keep = {k: lib.eovae_get_option(k) for k in (b'c8_w4', b'c8_mx', b'c8_wgrad_corr', b'c8_q16')}
     L.check(lib.eovae_set_option(b'c8_mx', 1), 'set_option')
     L.check(lib.eovae_set_option(b'c8_wgrad_corr', 0), 'set_option')
     yield
     ops.CONV_PRECISION = old
     for k, v in keep.items():
         lib.eovae_set_option(k, v)
+
+
+@pytest.fixture(params=[1, 0], ids=['q16', 'q32'])
+def mfma_shape(request):
+    """The one-wave kernel's two forms on MX records (library option c8_q16): 1 = conv_f16c8_q16.hip (16 x 16 MFMAs, correction
+    product over tap pairs, all-DMA feed; the default), 0 = conv_f16c8_w4.hip's MX instantiation (32 x 32 MFMAs)."""
+    from eo_vae_amd import lib as L
+    L.check(L.load().eovae_set_option(b'c8_q16', request.param), 'set_option')
+    return request.param
 
 
 def set_opt(name, v):
@@ -113,8 +122,8 @@ def test_weight_pack_holds_the_emulated_operands(cout, cin):
             assert pad.numel() == 0 or pad.abs().max() == 0
 
 
-@pytest.mark.parametrize('n,c,cout,h,w', [(2, 64, 128, 32, 64), (5, 128, 256, 64, 128), (1, 192, 128, 16, 32)])
-def test_forward_on_records_equals_the_emulated_product(n, c, cout, h, w):
+@pytest.mark.parametrize('n,c,cout,h,w', [(2, 64, 128, 32, 64), (5, 128, 256, 64, 128), (1, 192, 128, 16, 32), (3, 64, 128, 48, 96)])
+def test_forward_on_records_equals_the_emulated_product(n, c, cout, h, w, mfma_shape):
     from eo_vae_amd import ops
     from oracle import mx_emul as M
     torch.manual_seed(c + h)
@@ -180,7 +189,7 @@ def test_resnet_block_with_and_without_mx():
 
 
 @pytest.mark.parametrize('kernel', [0, 1])
-def test_both_forward_kernels_read_mx_records(kernel):
+def test_both_forward_kernels_read_mx_records(kernel, mfma_shape):
     """The 8-wave kernel (small grids: the 512-channel 32 x 32 layers) and the one-wave kernel on the same MX records."""
     from eo_vae_amd import ops
     from oracle import mx_emul as M

@@ -36,24 +36,29 @@ for cin, cout, hw in shapes:
         xrec = ops.group_norm_silu(x, g1, g0, 32, 1e-6, True, True)                  # format 1: f16 | e5m2 halves
         xmx = ops.group_norm_silu(x, g1, g0, 32, 1e-6, True, True, cout=cout)        # format 2 where the layer takes it
     have_mx = ops.packed_format(xmx) == 2
-    # variant '2' = the w4 kernel on MX operand records: correction product on block-scaled FP6 operands (round 5)
-    xin = lambda v: (xmx, 2) if v == '2' else (xrec, 1)
+    # variant '2' = the w4 kernel on MX operand records: correction product on block-scaled FP6 operands (round 5);
+    # variant '3' = the same records through conv_f16c8_q16.hip (16 x 16 MFMAs, all-DMA feed; library option c8_q16)
+    xin = lambda v: (xmx, 2) if v in '23' else (xrec, 1)
     cases = {
         'fwd rec+gn+res': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xin(v)[0]), None, L.ptr(wp), L.ptr(bias), L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, xin(v)[1], L.ptr(gns), 32, None, L.stream()),
         'fwd rec+gn    ': lambda v: lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xin(v)[0]), None, L.ptr(wp), L.ptr(bias), None, L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, xin(v)[1], L.ptr(gns), 32, None, L.stream()),
         'dgrad fp32+amax': lambda v: lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()),
     }
-    variants = '012' if have_mx else '01'
+    variants = '0123' if have_mx else '01'
     best = {(k, v): 1e9 for k in cases for v in variants}
     for rnd in range(3):
         for k, f in cases.items():
             for v in variants:
-                if v == '2' and k.startswith('dgrad'):
+                if v in '23' and k.startswith('dgrad'):
                     continue
                 lib.eovae_set_option(b'c8_w4', 0 if v == '0' else 1)
+                lib.eovae_set_option(b'c8_q16', 1 if v == '3' else 0)
                 best[(k, v)] = min(best[(k, v)], timeit(lambda: f(v)))
     for k in cases:
         t0, t1 = best[(k, '0')], best[(k, '1')]
         t2 = best.get((k, '2'), 1e9)
+        t3 = best.get((k, '3'), 1e9)
         mx = f' | w4 mx-fp6 {t2:7.3f} ms {flops/t2/1e9:6.1f} TF x{t1/t2:.3f} of w4' if t2 < 1e8 else ''
+        if t3 < 1e8:
+            mx += f' | q16 {t3:7.3f} ms {flops/t3/1e9:6.1f} TF x{t2/t3:.3f} of mx'
         print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 {k}: 8-wave {t0:7.3f} ms {flops/t0/1e9:6.1f} TF | w4 {t1:7.3f} ms {flops/t1/1e9:6.1f} TF | x{t0/t1:.3f}{mx}', flush=True)
