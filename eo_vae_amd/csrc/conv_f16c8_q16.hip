@@ -64,6 +64,25 @@ __device__ __host__ constexpr int q_is_c(int p) { return ((p % QNPH) + QNPH) % Q
 __device__ __host__ constexpr int q_nw(int p) { return q_is_c(p + 3) ? 4 : 2; }
 __device__ __host__ constexpr int q_nh(int p) { return p <= 4 ? 2 : (p == 8 || p == 9) ? 3 : (p == 10 || p == 11) ? 2 : 0; }
 
+// Diagnostic build only (-DEOVAE_Q16_STAMP=1, tools/q16_stamps.py): shader-clock stamps of block 0's waves per tile -- start,
+// end of the phase sequence, end of the epilogue, 100-MHz clock -- in a buffer nothing else reads.
+#ifndef EOVAE_Q16_STAMP
+#define EOVAE_Q16_STAMP 0
+#endif
+#if EOVAE_Q16_STAMP
+__device__ unsigned long long q16_stamps[4 * 32 * 4];
+#define Q16_STAMP(id)                                                                                       \
+  do {                                                                                                      \
+    if (blockIdx.x == 0 && lane == 0 && rec < 32)                                                           \
+      q16_stamps[(wave * 32 + rec) * 4 + (id)] = (id) == 3 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define Q16_STAMP(id) do {} while (0)
+#endif
+#ifndef EOVAE_Q16_ABL
+#define EOVAE_Q16_ABL 0   // timing-only experiments (WRONG results): 1 no s_nop in front of the correction MFMAs, 2 no output stores,
+                          // 4 every tile of a block stored to the same place (the output stays in the caches)
+#endif
 template <int OFF>
 __device__ __forceinline__ void rd128(i32x4& d, unsigned a) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset");
@@ -72,9 +91,21 @@ __device__ __forceinline__ void rd128(i32x4& d, unsigned a) {
 __device__ __forceinline__ void mfma_f(f32x4& c, const i32x4& a, const i32x4& b) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// TAIL: the last MFMAs of a chunk carry their own s_nop 15 -- behind the chunk loop the compiler reads / moves accumulators
+// (epilogue), and it knows no MFMA hazard for registers an asm statement wrote
+template <bool TAIL = false>
 __device__ __forceinline__ void mfma_c(f32x4& c, const i32x6& a, const i32x6& b, int sa, int sb) {
+  if constexpr (TAIL) {
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\ts_nop 15"
+                 : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    return;
+  }
   // s_nop 1: the operands' last two dwords reach their six-register tuples through v_mov copies, and an MFMA may not read a
   // register a VALU instruction wrote less than two wait states earlier -- a hazard hipcc covers for its own MFMAs only
+  if (EOVAE_Q16_ABL & 1)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+                 : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+  else
   asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
                : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
@@ -95,7 +126,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   // take their (plain) accesses for possible readers of a pending DMA and drain vmcnt(0) -- the epilogue's stores
   // included -- in front of them
   __shared__ __attribute__((aligned(16))) unsigned char smem[QLDS];
-  __shared__ float gcell[4 * 2 * QBM];   // [wave][sum | sumsq][channel of the block]
+  __shared__ float gcell[4 * 2 * 4 * QBM];   // [wave][sum | sumsq][lane group][channel of the block]: with the images and the
+                                             // weight ring exactly the CU's 160 KiB
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -192,10 +224,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   //   f16:  K block g = channel octet g of the chunk.   A: weight unit [octet][row][16 B]; B: f16 image [octet][pixel][16 B]
   //   FP6:  K block g = (tap t + g / 2, part g % 2).     A: units of the two taps [tap][part][piece][row][16 B]; B: FP6 image
   //         pieces 2 (g % 2), 2 (g % 2) + 1 at the pixel shifted by THAT tap
-  const unsigned a_f = (unsigned)(QOFF_W + g * 2048 + li * 16);
-  const unsigned a_c = (unsigned)(QOFF_W + (g >> 1) * 8192 + (g & 1) * 4096 + li * 16);
-  const unsigned b_f = (unsigned)(QOFF_XF + g * QPPL + (wrow * QXW + li) * 16);
-  const unsigned b_c = (unsigned)(QOFF_X6 + 2 * (g & 1) * QPPL + (wrow * QXW + li) * 16);
+  const unsigned lds0 = (unsigned)(size_t)smem;   // the asm reads take LDS byte addresses
+  const unsigned a_f = lds0 + (unsigned)(QOFF_W + g * 2048 + li * 16);
+  const unsigned a_c = lds0 + (unsigned)(QOFF_W + (g >> 1) * 8192 + (g & 1) * 4096 + li * 16);
+  const unsigned b_f = lds0 + (unsigned)(QOFF_XF + g * QPPL + (wrow * QXW + li) * 16);
+  const unsigned b_c = lds0 + (unsigned)(QOFF_X6 + 2 * (g & 1) * QPPL + (wrow * QXW + li) * 16);
   const unsigned gsel = (unsigned)(g >> 1);
 
   f32x4 acc[8][8];   // [co tile of 16][pixel tile: row 0..3 x half 0..1]
@@ -246,15 +279,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   auto mma = [&](auto qc, auto ic, auto jc) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value, i = decltype(ic)::value, j = decltype(jc)::value;
     constexpr int pr = (i >> 1) & 1, t = i & 1;
+    // (pixels as the MFMA's A operand, weights as its B operand: a lane's four result registers are then four CONSECUTIVE
+    // PIXELS of one channel -- the epilogue stores them as they are)
     if constexpr (q < 9) {
-      mfma_f(acc[i][j], Ar[pr][t][0], Br[q & 1][j][0]);
+      mfma_f(acc[i][j], Br[q & 1][j][0], Ar[pr][t][0]);
     } else {
       // a fragment = 24 data bytes + scale dword in two adjacent 16-byte reads: the operand is the first six registers of
       // the eight, the scale the seventh
       const i32x8 a8 = __builtin_shufflevector(Ar[pr][t][0], Ar[pr][t][1], 0, 1, 2, 3, 4, 5, 6, 7);
       const i32x8 b8 = __builtin_shufflevector(Br[q & 1][j][0], Br[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
       const i32x6 a6 = __builtin_shufflevector(a8, a8, 0, 1, 2, 3, 4, 5), b6 = __builtin_shufflevector(b8, b8, 0, 1, 2, 3, 4, 5);
-      mfma_c(acc[i][j], a6, b6, a8[6], b8[6]);
+      mfma_c<(q == QNPH - 1 && i >= 6 && j == 7)>(acc[i][j], b6, a6, b8[6], a8[6]);
     }
   };
 
@@ -281,40 +316,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   // ---------------------------------------------------------------- GroupNorm partial sums
   auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {
     const int v = tid >> 7, c = tid & 127;
-    float t = (gcell[(0 * 2 + v) * QBM + c] + gcell[(1 * 2 + v) * QBM + c]) + (gcell[(2 * 2 + v) * QBM + c] + gcell[(3 * 2 + v) * QBM + c]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {   // fixed order
+      const float* cw = gcell + ((w * 2 + v) * 4) * QBM + c;
+      t += (cw[0] + cw[QBM]) + (cw[2 * QBM] + cw[3 * QBM]);
+    }
     const int cpg = 1 << a.gn_shift;   // 4..64 channels per group (eligibility): inside one wave's 64 channels
     for (int s = 1; s < cpg && s < 64; s <<= 1) t += __shfl_xor(t, s, 64);
     if ((c & (cpg - 1)) == 0) atomicAdd(a.gn_sums + ((size_t)tn * a.gn_groups + ((tcb + c) >> a.gn_shift)) * 2 + v, (double)t);
   };
 
   // ---------------------------------------------------------------- epilogue
-  // acc[i][j][q]: channel 16 i + 4 g + q, pixel (row j >> 1, column 16 (j & 1) + li).  The 4 channels x 4 pixels of a lane
-  // quad are transposed inside the quad (DPP), so that lane 4 pq + m owns channel 4 g + m at pixels 4 pq .. 4 pq + 3 and
-  // every load / store moves 16 bytes per lane (conv_f16c8_w4.hip).
-  auto quad_transpose = [&](float (&v)[4], bool e0, bool e1) __attribute__((always_inline)) {
-#pragma unroll
-    for (int c = 0; c < 4; c += 2) {   // lane bit 0 <-> register bit 0
-      const float send = e0 ? v[c] : v[c + 1];
-      const float rcv = dpp_quad<0xB1>(send);
-      v[c] = e0 ? rcv : v[c];
-      v[c + 1] = e0 ? v[c + 1] : rcv;
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {      // lane bit 1 <-> register bit 1
-      const float send = e1 ? v[c] : v[c + 2];
-      const float rcv = dpp_quad<0x4E>(send);
-      v[c] = e1 ? rcv : v[c];
-      v[c + 2] = e1 ? v[c + 2] : rcv;
-    }
-  };
-  auto row_ror = [](float x, auto nc) __attribute__((always_inline)) {
-    constexpr int n = decltype(nc)::value;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + n, 0xf, 0xf, false));
-  };
+  // acc[i][j][q]: channel 16 i + li, pixel (row j >> 1, column 16 (j & 1) + 4 g + q): four consecutive pixels of one channel
+  // per lane, so every load / store moves 16 bytes per lane with no transposition (a wave instruction covers 16 channel
+  // planes x 64 bytes).  The 32 x 32 form has to transpose 4 x 4 blocks inside lane quads for that (conv_f16c8_w4.hip: ~8 VALU
+  // instructions per value -- 16 k cycles per tile at one wave per SIMD, profiles/r05w_q16_epi_abl.log).
   auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
     const int co_blk = t.cob * QBM;
-    const int m = lane & 3, pq = (lane >> 2) & 3;
-    const bool e0 = lane & 1, e1 = lane & 2;
     // buffer addressing and no branch: an absent residual / bias is a descriptor of zero bytes (loads return 0)
     const unsigned span = (unsigned)(QBM * out_plane * 4);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -323,10 +342,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
         const_cast<float*>(a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, a.res ? span : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias + co_blk : a.y), 0, a.bias ? (unsigned)(QBM * 4) : 0u, 0x00020000);
-    const int lot = (int)(((size_t)(4 * g + m) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * pq) * 4);
-    const int lob = (4 * g + m) * 4;
+    const int lot = (int)(((size_t)li * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * g) * 4);
+    const int lob = li * 4;
     const int tile16 = (int)(16 * out_plane * 4), rowb = a.Wout * 4;
-    float* const cell = gcell + wave * 2 * QBM;
+    float* const cell = gcell + wave * 8 * QBM + g * QBM + li;
     // one co tile (16 channels x the wave's 4 rows x 32 pixels = 8 accumulators) at a time; the residual of the next co tile
     // is requested while this one is written
     f32x4 rv[2][8];
@@ -344,27 +363,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = acc[i][j][k];
-        quad_transpose(w, e0, e1);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          o[k] = __builtin_fmaf(w[k], xinv, bias1) + rv[i & 1][j][k];
+          o[k] = __builtin_fmaf(acc[i][j][k], xinv, bias1) + rv[i & 1][j][k];
           sv += o[k];
           qv = __builtin_fmaf(o[k], o[k], qv);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64, 0);
+        if (!(EOVAE_Q16_ABL & 2))
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64, 0);
+        else
+          asm volatile("" :: "v"(o));
       }
-      // statistics of the following GroupNorm: the four pixel quartets (lane bits 2, 3) of a channel summed by row rotations;
-      // written unconditionally, read by gn_flush() only when the caller asked for them
-      sv += row_ror(sv, std::integral_constant<int, 4>{}); qv += row_ror(qv, std::integral_constant<int, 4>{});
-      sv += row_ror(sv, std::integral_constant<int, 8>{}); qv += row_ror(qv, std::integral_constant<int, 8>{});
-      if (pq == 0) {
-        cell[16 * i + 4 * g + m] = sv;
-        cell[QBM + 16 * i + 4 * g + m] = qv;
-      }
+      // statistics of the following GroupNorm: every lane's partial (its four pixels x eight pixel tiles of one channel),
+      // folded over lane groups and waves by gn_flush().  Written unconditionally, read only when the caller asked for them.
+      // (A butterfly over the lane groups by ds_bpermute -- __shfl_xor -- left wrong values in the OUTPUT of the first co
+      // tile: profiles/r05w notes; plain stores instead.)
+      cell[16 * i] = sv;
+      cell[4 * QBM + 16 * i] = qv;
     });
   };
 
@@ -392,7 +408,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   }
 
   // ---------------------------------------------------------------- main loop
+#if EOVAE_Q16_STAMP
+  int rec = 0;
+#endif
   for (; tile < a.ntiles; tile += gridDim.x) {
+    Q16_STAMP(0);
+    Q16_STAMP(3);
     const bool has_next_tile = tile + (int)gridDim.x < a.ntiles;
     Tile nxt = cur;
     if (has_next_tile) nxt = decode(tile + gridDim.x);
@@ -466,8 +487,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
       });
       P += QNPH;
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs' last results (hazards the compiler does not see)
+    Q16_STAMP(1);
+    if (EOVAE_Q16_ABL & 4) {
+      Tile fake = cur;
+      fake.n = (int)(blockIdx.x % a.N); fake.oy0 = 0; fake.ox0 = (int)((blockIdx.x / a.N) % a.tiles_x) * 32; fake.cob = 0;
+      epilogue_tile(fake);
+    } else
     epilogue_tile(cur);
+    Q16_STAMP(2);
+#if EOVAE_Q16_STAMP
+    ++rec;
+#endif
     zero_acc();
     if (a.gn_sums) {   // uniform.  The cells are rewritten by the next epilogue, a whole tile later.
       barrier();       // (raw: __syncthreads() carries a release fence = vmcnt(0), i.e. a wait for the epilogue's stores)
@@ -479,6 +509,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
 }
 
 }  // namespace
+
+#if EOVAE_Q16_STAMP
+extern "C" int eovae_debug_q16_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(q16_stamps), bytes < sizeof(q16_stamps) ? bytes : sizeof(q16_stamps));
+}
+#endif
 
 bool eovae_c8_q16_eligible(const ConvCArgs& a) {
   return eovae_opt(EOVAE_OPT_C8_Q16) != 0 && a.packed == 2 && a.x6 != nullptr && a.Hout % 16 == 0 && (!a.gn_sums || a.gn_shift <= 6) &&
