@@ -83,6 +83,12 @@ __device__ unsigned long long q16_stamps[4 * 32 * 4];
 #define EOVAE_Q16_ABL 0   // timing-only experiments (WRONG results): 1 no s_nop in front of the correction MFMAs, 2 no output stores,
                           // 4 every tile of a block stored to the same place (the output stays in the caches)
 #endif
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+template <int OFF>
+__device__ __forceinline__ void rd96(i32x3& d, unsigned a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset");
+  asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+}
 template <int OFF>
 __device__ __forceinline__ void rd128(i32x4& d, unsigned a) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset");
@@ -241,8 +247,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
         for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
   };
   // fragment registers: A streamed by co-tile pairs [pair parity][tile][lo | hi], B held per phase [phase parity][tile][lo | hi]
-  // (f16 fragments use [..][0] only)
-  i32x4 Ar[2][2][2], Br[2][8][2];
+  // FP6 fragments: 16 bytes of codes in *r[..], the remaining 8 bytes + the scale dword in *h[..] (ds_read_b96: the pad dword of
+  // a 32-byte operand is never read -- an eighth less LDS traffic in the correction phases, which the LDS paces)
+  i32x4 Ar[2][2], Br[2][8];
+  i32x3 Ah[2][2], Bh[2][8];
 
   // A fragments of co-tile pair c2 of a phase whose ring slot starts at byte `sb` (runtime), into Ar[c2 & 1]
   auto read_a = [&](auto isc, auto c2c, unsigned sb) __attribute__((always_inline)) {
@@ -252,11 +260,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if constexpr (ISC) {
-        if (t == 0) { rd128<(2 * c2) * 256>(Ar[c2 & 1][0][0], base); rd128<(2 * c2) * 256 + 2048>(Ar[c2 & 1][0][1], base); }
-        else { rd128<(2 * c2 + 1) * 256>(Ar[c2 & 1][1][0], base); rd128<(2 * c2 + 1) * 256 + 2048>(Ar[c2 & 1][1][1], base); }
+        if (t == 0) { rd128<(2 * c2) * 256>(Ar[c2 & 1][0], base); rd96<(2 * c2) * 256 + 2048>(Ah[c2 & 1][0], base); }
+        else { rd128<(2 * c2 + 1) * 256>(Ar[c2 & 1][1], base); rd96<(2 * c2 + 1) * 256 + 2048>(Ah[c2 & 1][1], base); }
       } else {
-        if (t == 0) rd128<(2 * c2) * 256>(Ar[c2 & 1][0][0], base);
-        else rd128<(2 * c2 + 1) * 256>(Ar[c2 & 1][1][0], base);
+        if (t == 0) rd128<(2 * c2) * 256>(Ar[c2 & 1][0], base);
+        else rd128<(2 * c2 + 1) * 256>(Ar[c2 & 1][1], base);
       }
     }
   };
@@ -265,14 +273,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
     constexpr int q = decltype(qc)::value, j = decltype(jc)::value, jr = j >> 1, hx = j & 1;
     if constexpr (q < 9) {
       constexpr int ky = q / 3, kx = q - 3 * ky;
-      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16>(Br[q & 1][j][0], b_f);
+      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16>(Br[q & 1][j], b_f);
     } else {
       constexpr int t0 = 2 * (q - 9), ky = t0 / 3, kx = t0 - 3 * ky;
       constexpr int t1 = t0 + 1 < 9 ? t0 + 1 : t0, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
       constexpr int delta = ((ky1 - ky) * QXW + (kx1 - kx)) * 16;   // the second tap's pixel shift against the first's
       const unsigned base = b_c + gsel * (unsigned)delta;
-      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16>(Br[q & 1][j][0], base);
-      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16 + QPPL>(Br[q & 1][j][1], base);
+      rd128<((ky + jr) * QXW + kx + 16 * hx) * 16>(Br[q & 1][j], base);
+      rd96<((ky + jr) * QXW + kx + 16 * hx) * 16 + QPPL>(Bh[q & 1][j], base);
     }
   };
   // MFMA (co tile i, pixel tile j) of phase q
@@ -282,14 +290,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
     // (pixels as the MFMA's A operand, weights as its B operand: a lane's four result registers are then four CONSECUTIVE
     // PIXELS of one channel -- the epilogue stores them as they are)
     if constexpr (q < 9) {
-      mfma_f(acc[i][j], Br[q & 1][j][0], Ar[pr][t][0]);
+      mfma_f(acc[i][j], Br[q & 1][j], Ar[pr][t]);
     } else {
-      // a fragment = 24 data bytes + scale dword in two adjacent 16-byte reads: the operand is the first six registers of
-      // the eight, the scale the seventh
-      const i32x8 a8 = __builtin_shufflevector(Ar[pr][t][0], Ar[pr][t][1], 0, 1, 2, 3, 4, 5, 6, 7);
-      const i32x8 b8 = __builtin_shufflevector(Br[q & 1][j][0], Br[q & 1][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
-      const i32x6 a6 = __builtin_shufflevector(a8, a8, 0, 1, 2, 3, 4, 5), b6 = __builtin_shufflevector(b8, b8, 0, 1, 2, 3, 4, 5);
-      mfma_c<(q == QNPH - 1 && i >= 6 && j == 7)>(acc[i][j], b6, a6, b8[6], a8[6]);
+      // a fragment = 24 data bytes + scale dword: the operand is a six-register tuple (16 + 8 bytes), the scale the last dword
+      // of the second read
+      i32x6 a6, b6;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a6[e] = Ar[pr][t][e]; b6[e] = Br[q & 1][j][e]; }
+      a6[4] = Ah[pr][t][0]; a6[5] = Ah[pr][t][1];
+      b6[4] = Bh[q & 1][j][0]; b6[5] = Bh[q & 1][j][1];
+      mfma_c<(q == QNPH - 1 && i >= 6 && j == 7)>(acc[i][j], b6, a6, Bh[q & 1][j][2], Ah[pr][t][2]);
     }
   };
 
@@ -302,15 +312,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   // are therefore passed through an empty asm statement: their consumers depend on THAT.
   auto landed_a = [&](int pr) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(Ar[pr][t][u]));
+    for (int t = 0; t < 2; ++t) {
+      asm volatile("" : "+v"(Ar[pr][t]));
+      asm volatile("" : "+v"(Ah[pr][t]));
+    }
   };
   auto landed_b = [&](int par) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(Br[par][j][u]));
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("" : "+v"(Br[par][j]));
+      asm volatile("" : "+v"(Bh[par][j]));
+    }
   };
 
   // ---------------------------------------------------------------- GroupNorm partial sums
