@@ -108,6 +108,19 @@ def traffic_ratios(src, alg_bytes):
         return None
 
 
+def one_wave_roofline(timer, kind, peak, elapsed):
+    """The other of the two one-wave-per-SIMD kernels (kind 1: conv_f16c8_w4.hip, 2: conv_f16c8_q16.hip), measured like `roofline`."""
+    ms, flops, n = timer.totals(kind)
+    if n == 0 or ms <= 0:
+        return None
+    ach = flops / (ms * 1e-3)
+    name = {1: 'conv3x3_f16c8_w4_kernel (32x32 MFMAs: data gradients, fp32 / format-1 inputs)',
+            2: 'conv3x3_f16c8_q16_kernel (16x16 MFMAs, all-DMA feed: forward on MX operand records)'}[kind]
+    return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s',
+            'frac': round(ach / peak, 4), 'launches': n, 'achieved_per_launch_ms': round(ms / n, 4),
+            'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
+
+
 def conv8_roofline(timer, peak, elapsed):
     """The 3x3 forward / data-gradient launches that stay on the 8-wave kernel (sub-pixel and space-to-depth forms, grids
     below two 16-row tiles per CU), measured like `roofline`."""
@@ -439,10 +452,14 @@ def main():
         prec = ops.CONV_PRECISION
         # f16c8: the dominant kernel is the one-wave-per-SIMD kernel (kind 1); the launches the 8-wave kernel takes
         # (sub-pixel / space-to-depth forms, small grids) are reported beside it as `roofline_conv8`
-        dom = 1 if prec == 'f16c8' and timer.totals(1)[2] > 0 else None
+        # (kind 2, round 5: the layers on MX operand records run conv_f16c8_q16.hip -- 16 x 16 MFMAs, all-DMA feed; the
+        # dominant kernel is whichever of the two one-wave kernels holds more of the step, the other is reported beside it)
+        dom = None
+        if prec == 'f16c8' and (timer.totals(1)[2] > 0 or timer.totals(2)[2] > 0):
+            dom = 1 if timer.totals(1)[0] >= timer.totals(2)[0] else 2
         k_ms, k_flops, k_n = timer.totals(dom)
-        traffic, traffic_source = pmc_traffic(('conv3x3_f16c8_w4_kernel' if dom else 'conv3x3_f16c8_kernel')
-                                              if prec == 'f16c8' else 'conv3x3_bf16_kernel')
+        dom_name = {1: 'conv3x3_f16c8_w4_kernel', 2: 'conv3x3_f16c8_q16_kernel'}.get(dom, 'conv3x3_f16c8_kernel')
+        traffic, traffic_source = pmc_traffic(dom_name if prec == 'f16c8' else 'conv3x3_bf16_kernel')
         achieved = k_flops / (k_ms * 1e-3) if k_ms > 0 else 0.0
         r_hbm = PEAK_HBM / (Q_STEP_PER_IMG + Q_STEP_FIXED / args.batch)  # img/s per GPU at the HBM roof
         f_img = F_STEP_PER_IMG.get(C, 2.69e12)
@@ -451,15 +468,17 @@ def main():
             path = 'fp32-input MFMA implicit GEMM (exact fp32)'
         elif prec == 'f16c8':
             peak, dtype = PEAK_BF16_MFMA, 'f16c8'
-            kname = ('conv3x3_f16c8_w4_kernel (plain 3x3 conv fwd + data-grad: one wave per SIMD, 4x4 register blocking, '
-                     'f16 product + one correction product: block-scaled MX-FP6 on operand-record inputs, fp8 on fp32 inputs)'
-                     if dom else
-                     'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)')
+            kname = {1: 'conv3x3_f16c8_w4_kernel (plain 3x3 layers, one wave per SIMD, 4x4 blocks of 32x32 MFMAs: the data gradients '
+                        '(fp32 inputs converted in the kernel, fp8 correction product) and the forward of layers without MX records)',
+                     2: 'conv3x3_f16c8_q16_kernel (plain 3x3 layers on MX operand records -- the forward: one wave per SIMD, 8x8 '
+                        'blocks of 16x16 MFMAs, MX-FP6 correction product over tap pairs, halo and weights by LDS-DMA)'
+                     }.get(dom, 'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)')
             lib_ = ops.L.load()
             mx_on, wcorr = lib_.eovae_get_option(b'c8_mx') != 0, lib_.eovae_get_option(b'c8_wgrad_corr') != 0
-            path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) on v_mfma_f32_32x32x16_f16 + ONE K-concatenated block-scaled '
-                    'correction product [x_lo|x_hi].[w_hi|w_lo] on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate (~1e-5 per '
-                    'product): '
+            path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) + ONE K-concatenated block-scaled correction product '
+                    '[x_lo|x_hi].[w_hi|w_lo], fp32 accumulate (~1e-5 per product), on v_mfma_f32_32x32x16_f16 / '
+                    'v_mfma_scale_f32_32x32x64_f8f6f4 or -- forward on MX records, plain weight gradients -- on the 16x16 forms '
+                    '(v_mfma_f32_16x16x32_f16 / v_mfma_scale_f32_16x16x128_f8f6f4 over tap pairs: the chip holds a higher clock on them): '
                     + ('MX-FP6 (e2m3, per-32-channel E8M0 scales; 1.64 MFMA units per product) in the forward of the layers '
                        'GroupNorm feeds with MX operand records, ' if mx_on else '')
                     + 'fp8 (e5m2 / e4m3; 2 units) in the data gradient and on fp32 inputs; weight gradients: '
@@ -499,6 +518,7 @@ def main():
                          'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
                          'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
             'roofline_conv8': conv8_roofline(timer, peak, elapsed) if dom else None,
+            'roofline_other_one_wave': one_wave_roofline(timer, 3 - dom, peak, elapsed) if dom else None,
             'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),
             # f16c8: forward = half of the conv flops, ~0.86 of it (the plain layers behind a GroupNorm) on the MX-FP6 form
             'ceiling': ceiling(timer.totals()[1] / args.steps, wtimer.totals()[1] / args.steps, args.batch, ips / world,

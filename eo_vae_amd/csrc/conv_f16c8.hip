@@ -1905,16 +1905,19 @@ static int c8_n_cu() {
 }
 
 // Which kernel eovae_conv3x3_f16c8_fwd launches for these arguments: 1 = conv3x3_f16c8_w4_kernel (one wave per SIMD, 16-row
-// tiles; plain layers that give every CU two tiles), 0 = conv3x3_f16c8_kernel (8 waves, 8-row tiles; every other form).
+// tiles; plain layers that give every CU two tiles), 2 = conv3x3_f16c8_q16_kernel (the same walk on 16 x 16 MFMAs with an
+// all-DMA feed: those layers on MX operand records), 0 = conv3x3_f16c8_kernel (8 waves, 8-row tiles; every other form).
 // For callers that attribute measured time to a kernel (bench.py); no launch, no device work beyond the first
 // property query.
 int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
                               int xpacked) {
   ConvCArgs a;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout; a.mode = mode;
-  a.packed = xpacked; a.x6 = nullptr; a.mx = 0;
+  a.packed = xpacked; a.x6 = nullptr; a.mx = 0; a.gn_sums = nullptr; a.gn_shift = 0;
+  a.nchunk = Cin / 32; a.ncob = cdiv(Cout, 128);
   const int n_cu = c8_n_cu();
-  return (n_cu > 0 && subpix == 0 && eovae_c8_w4_eligible(a, subpix, n_cu)) ? 1 : 0;
+  if (!(n_cu > 0 && subpix == 0 && eovae_c8_w4_eligible(a, subpix, n_cu))) return 0;
+  return (eovae_opt(EOVAE_OPT_C8_W4_NI) != 2 && eovae_c8_q16_eligible(a)) ? 2 : 1;
 }
 
 // 3x3 stride-1 conv / data gradient with f16c8 operands.  Arguments as eovae_conv3x3_bf16_fwd; the GEMM K

@@ -70,6 +70,12 @@ __device__ __host__ constexpr int q_nh(int p) { return p <= 4 ? 2 : (p == 8 || p
 #define EOVAE_Q16_STAMP 0
 #endif
 #if EOVAE_Q16_STAMP
+__device__ unsigned long long q16_phase_stamps[4 * 14 * 4];   // STAMP == 2: [wave][phase][barrier in | barrier out | MFMAs done | requests landed]
+#define Q16_PSTAMP(p, id)                                                                                  \
+  do {                                                                                                      \
+    if (EOVAE_Q16_STAMP == 2 && blockIdx.x == 0 && lane == 0 && rec == 1 && chunk == 1)                     \
+      q16_phase_stamps[(wave * 14 + (p)) * 4 + (id)] = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
 __device__ unsigned long long q16_stamps[4 * 32 * 4];
 #define Q16_STAMP(id)                                                                                       \
   do {                                                                                                      \
@@ -78,6 +84,7 @@ __device__ unsigned long long q16_stamps[4 * 32 * 4];
   } while (0)
 #else
 #define Q16_STAMP(id) do {} while (0)
+#define Q16_PSTAMP(p, id) do {} while (0)
 #endif
 #ifndef EOVAE_Q16_ABL
 #define EOVAE_Q16_ABL 0   // timing-only experiments (WRONG results): 1 no s_nop in front of the correction MFMAs, 2 no output stores,
@@ -115,6 +122,19 @@ __device__ __forceinline__ void mfma_c(f32x4& c, const i32x6& a, const i32x6& b,
   asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
                : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
+// placement of a pair's side work: index of the MFMA (0..15) it follows
+#ifndef EOVAE_Q16_MM_DMA
+#define EOVAE_Q16_MM_DMA 1
+#endif
+#ifndef EOVAE_Q16_MM_A
+#define EOVAE_Q16_MM_A 3
+#endif
+#ifndef EOVAE_Q16_MM_B0
+#define EOVAE_Q16_MM_B0 7
+#endif
+#ifndef EOVAE_Q16_MM_B1
+#define EOVAE_Q16_MM_B1 11
+#endif
 #ifndef EOVAE_Q16_SAFE
 #define EOVAE_Q16_SAFE 0   // bisection: 1 every counted vmcnt wait becomes vmcnt(0), 2 every counted lgkmcnt wait lgkmcnt(0)
 #endif
@@ -443,7 +463,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
         constexpr int pn = (p + 1) % QNPH;
         constexpr bool ISC = p >= 9, NISC = pn >= 9;
         using PN = std::integral_constant<int, pn>;
+        Q16_PSTAMP(p, 0);
         barrier();   // phase p's weights, the images it reads and its first fragments are there
+        Q16_PSTAMP(p, 1);
         landed_a(0);
         landed_b(p & 1);
         const unsigned sb = ((P + p) & 3u) * QWSLOT, sbn = ((P + p + 1) & 3u) * QWSLOT;
@@ -458,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
             constexpr int j = mm >> 1, i = 2 * c2 + (mm & 1);
             mma(pc, std::integral_constant<int, i>{}, std::integral_constant<int, j>{});
             // the phase's other work, one piece behind every MFMA pair
-            if constexpr (mm == 1) {
+            if constexpr (mm == EOVAE_Q16_MM_DMA) {
               if constexpr (c2 == 0) {   // weights of phase p + 3
                 if constexpr (p + 3 < QNPH) request_w(std::integral_constant<int, p + 3>{}, cur.cob, chunk, (P + p + 3) & 3u);
                 else request_w(std::integral_constant<int, p + 3 - QNPH>{}, xt.cob, xchunk, (P + p + 3) & 3u);
@@ -471,12 +493,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
                 if constexpr (p == 11) { dma_x(sf, xf_dst, 8); dma_x(sf, xf_dst, 9); }
               }
             }
-            if constexpr (mm == 3) {     // A fragments of the next co-tile pair (of the next phase behind the last pair)
+            if constexpr (mm == EOVAE_Q16_MM_A) {     // A fragments of the next co-tile pair (of the next phase behind the last pair)
               if constexpr (c2 < 3) read_a(std::integral_constant<bool, ISC>{}, std::integral_constant<int, c2 + 1>{}, sb);
               else read_a(std::integral_constant<bool, NISC>{}, std::integral_constant<int, 0>{}, sbn);
             }
-            if constexpr (mm == 7) read_b(PN{}, std::integral_constant<int, 2 * c2>{});
-            if constexpr (mm == 11) read_b(PN{}, std::integral_constant<int, 2 * c2 + 1>{});
+            if constexpr (mm == EOVAE_Q16_MM_B0) read_b(PN{}, std::integral_constant<int, 2 * c2>{});
+            if constexpr (mm == EOVAE_Q16_MM_B1) read_b(PN{}, std::integral_constant<int, 2 * c2 + 1>{});
             if constexpr (mm == 15) {    // the next pair's A fragments have landed; the B reads behind them may be outstanding
               if constexpr (c2 < 3) {
                 wait_lgkm<NISC ? 4 : 2>();
@@ -485,6 +507,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
             }
           });
         });
+        Q16_PSTAMP(p, 2);
         // everything requested before this phase has landed (its own requests may be outstanding).  Behind a tile's last
         // phase: all of it -- the epilogue's stores come next in the queue, and a counted wait behind them would wait
         // for them too; the first phase of a tile therefore does not wait (its needs were met here).
@@ -496,6 +519,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
         } else {
           wait_vm<q_nw(p) + q_nh(p)>();
         }
+        Q16_PSTAMP(p, 3);
       });
       P += QNPH;
     }
@@ -523,13 +547,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
 }  // namespace
 
 #if EOVAE_Q16_STAMP
+extern "C" int eovae_debug_q16_phase_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(q16_phase_stamps), bytes < sizeof(q16_phase_stamps) ? bytes : sizeof(q16_phase_stamps));
+}
 extern "C" int eovae_debug_q16_stamps(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(q16_stamps), bytes < sizeof(q16_stamps) ? bytes : sizeof(q16_stamps));
 }
 #endif
 
+// (a.x6 is not looked at: eovae_conv3x3_f16c8_which() asks without pointers; the entry sets it for every packed == 2 call)
 bool eovae_c8_q16_eligible(const ConvCArgs& a) {
-  return eovae_opt(EOVAE_OPT_C8_Q16) != 0 && a.packed == 2 && a.x6 != nullptr && a.Hout % 16 == 0 && (!a.gn_sums || a.gn_shift <= 6) &&
+  return eovae_opt(EOVAE_OPT_C8_Q16) != 0 && a.packed == 2 && a.Hout % 16 == 0 && (!a.gn_sums || a.gn_shift <= 6) &&
          (size_t)a.Hin * a.Win * 16 < (1ull << 31) && (size_t)9 * a.nchunk * a.ncob * C8_WTILE < (1ull << 32);
 }
 

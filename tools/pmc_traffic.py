@@ -9,7 +9,7 @@ for c in ['FETCH_SIZE', 'WRITE_SIZE']:
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != c:
                 continue
-            for k in ['conv3x3_f16c8_w4_kernel', 'conv3x3_f16c8_kernel', 'conv3x3_bf16_kernel', 'wgrad3x3_bf16_kernel', 'wgrad3x3_f16c8_rows_kernel', 'wgrad3x3_f16c8_kernel', 'gemm_bf16_kernel',
+            for k in ['conv3x3_f16c8_q16_kernel', 'conv3x3_f16c8_w4_kernel', 'conv3x3_f16c8_kernel', 'conv3x3_bf16_kernel', 'wgrad3x3_bf16_kernel', 'wgrad3x3_f16c8_rows_kernel', 'wgrad3x3_f16c8_kernel', 'gemm_bf16_kernel',
                       'gn_apply_packed_kernel', 'gn_bwd_fused_pipe_kernel<true, true', 'gn_bwd_fused_pipe_kernel<true, false',
                       'gn_bwd_fused_kernel', 'gn_bwd_reduce_kernel', 'gn_bwd_apply_kernel']:
                 if k in r['Kernel_Name']:

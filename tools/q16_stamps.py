@@ -45,3 +45,18 @@ for wave in (0, 3):
     if n >= 3:
         c = 100.0 * (t[wave, n - 1, 0] - t[wave, 1, 0]) / (t[wave, n - 1, 3] - t[wave, 1, 3])
         print(f'wave {wave}: shader clock {c:.0f} MHz')
+
+try:
+    fp = C.CDLL(L.LIB_PATH).eovae_debug_q16_phase_stamps
+    fp.argtypes = [C.c_void_p, C.c_size_t]
+    pb = np.zeros(4 * 14 * 4, dtype=np.uint64)
+    if fp(pb.ctypes.data, pb.nbytes) == 0 and pb.any():
+        q = pb.reshape(4, 14, 4).astype(np.int64)
+        for wave in (0, 3):
+            print(f'wave {wave}, second tile, chunk 1 -- per phase: wait at the barrier | MFMA block | wait for the requests | phase total')
+            for p in range(14):
+                r = q[wave, p]
+                nxt = q[wave, p + 1, 0] if p + 1 < 14 else r[3]
+                print(f'   phase {p:2d}: {int(r[1] - r[0]):5d} | {int(r[2] - r[1]):5d} | {int(r[3] - r[2]):5d} | {int(nxt - r[0]):5d}')
+except AttributeError:
+    pass
