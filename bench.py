@@ -121,6 +121,17 @@ def one_wave_roofline(timer, kind, peak, elapsed):
             'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
 
 
+def family_roofline(timer, peak, elapsed):
+    ms = timer.totals(1)[0] + timer.totals(2)[0]
+    flops = timer.totals(1)[1] + timer.totals(2)[1]
+    n = timer.totals(1)[2] + timer.totals(2)[2]
+    if n == 0 or ms <= 0:
+        return None
+    ach = flops / (ms * 1e-3)
+    return {'kernels': 'conv3x3_f16c8_w4_kernel + conv3x3_f16c8_q16_kernel', 'achieved': round(ach / 1e12, 2),
+            'frac': round(ach / peak, 4), 'launches': n, 'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
+
+
 def conv8_roofline(timer, peak, elapsed):
     """The 3x3 forward / data-gradient launches that stay on the 8-wave kernel (sub-pixel and space-to-depth forms, grids
     below two 16-row tiles per CU), measured like `roofline`."""
@@ -516,7 +527,10 @@ def main():
                          'traffic_ratio_vs_algorithmic': traffic_ratios(traffic_source, timer.bytes_total(dom) / max(k_n, 1)),
                          'algorithmic_bytes_per_launch': round(timer.bytes_total(dom) / max(k_n, 1)),
                          'achieved_per_launch_ms': round(k_ms / max(k_n, 1), 4), 'launches': k_n,
-                         'kernel_time_share': round(k_ms / (elapsed * 1e3), 4)},
+                         'kernel_time_share': round(k_ms / (elapsed * 1e3), 4),
+                         # the two one-wave-per-SIMD kernels together: the family rounds 3-4 reported as ONE kernel (their
+                         # `roofline` object), for the round-over-round comparison
+                         'one_wave_family': family_roofline(timer, peak, elapsed) if dom else None},
             'roofline_conv8': conv8_roofline(timer, peak, elapsed) if dom else None,
             'roofline_other_one_wave': one_wave_roofline(timer, 3 - dom, peak, elapsed) if dom else None,
             'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),

@@ -30,7 +30,9 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
     {"c8_pack_gather", "EOVAE_C8_PACK_GATHER", 0}, // per-layer weight packs by the per-element gather kernel (reference of the LDS-staged one)
     {"c8_mx", "EOVAE_C8_MX", 1},                   // MX-FP6 correction product (conv_f16c8_common.h); 0 = the fp8 form everywhere
     {"c8_wgrad_corr", "EOVAE_C8_WGRAD_CORR", 0},   // 1: the row-streaming weight gradients keep their fp8 correction product (r4); 0: f16 x f16 alone
-    {"c8_q16", "EOVAE_C8_Q16", 1},                 // 16 x 16 x 32 MFMAs where a kernel has that form (higher clock under load); 0: the 32 x 32 forms
+    {"c8_q16", "EOVAE_C8_Q16", 1},                 // 16 x 16 MFMAs where a kernel has that form (higher clock under load): 1 (default) record inputs
+                                                   // and the plain weight gradient; 2 the fp32-input data gradients too (measured 0.88-0.92 x the
+                                                   // 32 x 32 kernel: an experiment that stays tested); 0: the 32 x 32 forms
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};

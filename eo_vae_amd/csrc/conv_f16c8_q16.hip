@@ -30,7 +30,23 @@
 //   requested in phase 7; first reader: phase 13, which requests phase 0's B fragments).
 //   End of phase p: s_waitcnt vmcnt(requests of phase p) -- everything older has landed -- then the workgroup barrier.
 //
-// Restrictions (conv_f16c8_w4.hip runs otherwise): those of that kernel, MX operand records, library option c8_q16.
+// FP32IN (the data gradients: dY arrives as fp32): the same MFMA stream, the same LDS images -- written by the block itself.
+//   A thread takes halo pixels tid, tid + 256, tid + 512 with ALL 32 channels of the chunk (one buffer_load_dword per channel:
+//   64 consecutive pixels of a plane per instruction), so the 32-channel block scales of the MX-FP6 parts need no exchange
+//   between threads.  One pixel is in flight at a time (32 registers); it is converted IN PLACE in ~40 steps of two to four
+//   VALU instructions, one step behind each MFMA of a phase (pinned by scheduling barriers: hipcc would issue the block in one
+//   piece and stall the matrix pipes for it), and leaves as four ds_write_b128.  The images are single-buffered and free
+//   at different times, so a chunk is read TWICE (the second time from L2): pass 1 = f16 parts -> f16 image of the next chunk
+//   (phases 8, 10, 12), pass 2 = block-scaled FP6 of x and of x - f16(x) -> FP6 image of this chunk (phases 0, 2, 4).
+//   The weights still come by DMA.  conv_f16c8_w4.hip's fp32 path has the fp8 correction product (2 units); this one the
+//   MX-FP6 one (1.64) on the shape the chip clocks higher on.
+//   MEASURED SLOWER (profiles/r05z_q16f_*: 0.88-0.92 x conv_f16c8_w4.hip's fp32 path per layer): the seven staging phases of a chunk
+//   take 2.1-3.1 k cycles instead of 1.2 k -- the 192 buffer_load_dword of a chunk cost ~30 cycles of issue each beside the MFMAs
+//   (phase 6, which only loads, takes 2.3 k), the conversion steps the rest.  A planar fp32 input has no cheap way into per-pixel
+//   32-channel blocks; the path stays behind option value 2, tested (tests/test_gpu_mx.py), as the record of that.
+//
+// Restrictions (conv_f16c8_w4.hip runs otherwise): those of that kernel; MX operand records, or fp32 input with library option
+// c8_q16 = 2 (default 1: record inputs only).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -97,6 +113,21 @@ __device__ __forceinline__ void rd96(i32x3& d, unsigned a) {
   asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
 }
 template <int OFF>
+__device__ __forceinline__ void wr128(unsigned a, const i32x4& d) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset");
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(d), "n"(OFF) : "memory");
+}
+// mx6_quant (conv_f16c8_common.h) on values that already sit in two sixteen-register tuples (k = 0..15 | 16..31)
+__device__ __forceinline__ void mx6_quant16(const f32x16& a, const f32x16& b, float amax, i32x4& p0, i32x4& p1) {
+  typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+  const unsigned sb = mx6_scale_byte(amax);
+  const float div = __builtin_bit_cast(float, sb << 23);
+  u32x6 q;
+  asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(q) : "v"(a), "v"(b), "v"(div));
+  p0[0] = (int)q[0]; p0[1] = (int)q[1]; p0[2] = (int)q[2]; p0[3] = (int)q[3];
+  p1[0] = (int)q[4]; p1[1] = (int)q[5]; p1[2] = (int)sb; p1[3] = 0;
+}
+template <int OFF>
 __device__ __forceinline__ void rd128(i32x4& d, unsigned a) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
@@ -147,6 +178,7 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EOVAE_Q16_SAFE & 1) ? 0 : (N < 63 ? N : 63)) : "memory");
 }
 
+template <bool FP32IN>
 __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) {
   // the DMA targets / fragment sources; the GroupNorm cells live in an array of their own so that the compiler does not
   // take their (plain) accesses for possible readers of a pending DMA and drain vmcnt(0) -- the epilogue's stores
@@ -182,10 +214,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
     return t;
   };
 
-  float xinv = 1.f;   // records of a range-guarded input (none today): undone with the result, as conv_f16c8_w4.hip
+  auto lds0_ = [&]() __attribute__((always_inline)) { return (unsigned)(size_t)smem; };
+  float xs = 1.f, xinv = 1.f;   // range pre-scale of an fp32 input (amax to 2^13..2^14), undone with the result, as conv_f16c8_w4.hip
   if (a.xamax) {
     const unsigned bits = *a.xamax;
-    if (bits) xinv = pow2f(expo_of_bits(bits) - 13);
+    if (bits) {
+      const int e = expo_of_bits(bits);
+      xs = pow2f(13 - e);
+      xinv = pow2f(e - 13);
+    }
   }
 
   // ---------------------------------------------------------------- halo requests (wave = channel octet / FP6 piece)
@@ -219,6 +256,86 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr)(dst + k * 1024), 16, (int)xoff[k], 0, 0, 0);
   };
 
+  // ---------------------------------------------------------------- fp32 input: register staging (FP32IN)
+  unsigned foff[3];   // byte offset of the thread's k-th pixel in a channel plane of x, or out of range
+  auto setup_f = [&](const Tile& t) __attribute__((always_inline)) {
+    int th = tid;
+    asm volatile("" : "+v"(th));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int pix = th + 256 * k;
+      const int rr = (pix * 241) >> 13, cc = pix - QXW * rr;   // pix / 34 (exact below 1024 here: 241 / 8192 = 1 / 33.99)
+      const int vy = t.oy0 + rr - 1, vx = t.ox0 + cc - 1;
+      const bool ok = (pix < QNPX) & ((unsigned)vy < (unsigned)a.Hin) & ((unsigned)vx < (unsigned)a.Win);
+      foff[k] = ok ? (unsigned)(vy * a.Win + vx) * 4u : OOR;
+    }
+  };
+  const unsigned plane4 = (unsigned)(in_plane * 4);
+  auto srd_f = [&](const Tile& t, int chunk) __attribute__((always_inline)) {   // x [n][Cin][pixel] fp32, channels 32 chunk ..
+    const float* p = a.x + ((size_t)t.n * a.Cin + 32 * chunk) * in_plane;
+    // (the chunk's 32 planes: whether or not the range check adds the scalar offset, a valid lane stays inside and the
+    // out-of-range marker 2^31 stays outside)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 32u * plane4, 0x00020000);
+  };
+  f32x16 va, vb;         // the pixel in flight: channels 0..15 | 16..31
+  float ahi = 0.f, alo = 0.f;
+  int hp[16];            // pass 1: the sixteen f16 pairs
+  i32x4 q0, q1, q2, q3;  // pass 2: pieces of quant(x - f16 x) | quant(x)
+  const unsigned wpx = lds0_() + (unsigned)tid * 16u;   // LDS address of pixel `tid` in plane 0 of the f16 image
+  // two channels of the pixel's 32 per call: loads
+  auto ld_step = [&](const __amdgpu_buffer_rsrc_t& srd, int k, auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;   // 0..15
+    va[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)foff[k], (int)(j * plane4), 0));
+    vb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)foff[k], (int)((16 + j) * plane4), 0));
+  };
+  // pass 1, step s of 36: scale, f16 pairs, four writes into the f16 image (octet o at o * QPPL)
+  auto cv1_step = [&](int k, auto sc_) __attribute__((always_inline)) {
+    constexpr int s_ = decltype(sc_)::value;
+    if constexpr (s_ < 16) {
+      va[s_] *= xs;
+      vb[s_] *= xs;
+    } else if constexpr (s_ < 32) {
+      constexpr int q = s_ - 16;   // pair q = channels 2 q, 2 q + 1
+      const float v0 = q < 8 ? va[2 * q] : vb[2 * q - 16], v1 = q < 8 ? va[2 * q + 1] : vb[2 * q - 15];
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp[q]) : "v"(v0), "v"(v1));
+    } else if constexpr (s_ < 36) {
+      constexpr int o = s_ - 32;
+      i32x4 w;
+      w[0] = hp[4 * o]; w[1] = hp[4 * o + 1]; w[2] = hp[4 * o + 2]; w[3] = hp[4 * o + 3];
+      if (k < 2 || tid < 128) wr128<o * QPPL>(wpx + (unsigned)(k * 4096), w);   // (pixels beyond the plane's 640: no write)
+    }
+  };
+  // pass 2, step s of 38: scale + amax, quant(x), residuals in place + amax, quant(residual), four writes into the FP6 image
+  auto cv2_step = [&](int k, auto sc_) __attribute__((always_inline)) {
+    constexpr int s_ = decltype(sc_)::value;
+    if constexpr (s_ < 16) {
+      if constexpr (s_ == 0) { ahi = 0.f; alo = 0.f; }
+      va[s_] *= xs;
+      vb[s_] *= xs;
+      ahi = __builtin_fmaxf(ahi, __builtin_fmaxf(__builtin_fabsf(va[s_]), __builtin_fabsf(vb[s_])));
+    } else if constexpr (s_ == 16) {
+      mx6_quant16(va, vb, ahi, q2, q3);
+    } else if constexpr (s_ < 33) {
+      constexpr int q = s_ - 17;
+      const float v0 = q < 8 ? va[2 * q] : vb[2 * q - 16];
+      const float v1 = q < 8 ? va[2 * q + 1] : vb[2 * q - 15];
+      int hh;
+      float l0, l1;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v0), "v"(v1));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hh), "v"(v0));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hh), "v"(v1));
+      if constexpr (q < 8) { va[2 * q] = l0; va[2 * q + 1] = l1; }
+      else { vb[2 * q - 16] = l0; vb[2 * q - 15] = l1; }
+      alo = __builtin_fmaxf(alo, __builtin_fmaxf(__builtin_fabsf(l0), __builtin_fabsf(l1)));
+    } else if constexpr (s_ == 33) {
+      mx6_quant16(va, vb, alo, q0, q1);
+    } else if constexpr (s_ < 38) {
+      constexpr int pc_ = s_ - 34;   // piece 0, 1: residual; 2, 3: x
+      const i32x4& w = pc_ == 0 ? q0 : (pc_ == 1 ? q1 : (pc_ == 2 ? q2 : q3));
+      if (k < 2 || tid < 128) wr128<pc_ * QPPL>(wpx + (unsigned)(QOFF_X6 + k * 4096), w);
+    }
+  };
+
   // ---------------------------------------------------------------- weight requests: 8 KB units, two DMAs each
   const size_t wbytes = (size_t)9 * a.nchunk * a.ncob * C8_WTILE;
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wp), 0, (unsigned)wbytes, 0x00020000);
@@ -250,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   //   f16:  K block g = channel octet g of the chunk.   A: weight unit [octet][row][16 B]; B: f16 image [octet][pixel][16 B]
   //   FP6:  K block g = (tap t + g / 2, part g % 2).     A: units of the two taps [tap][part][piece][row][16 B]; B: FP6 image
   //         pieces 2 (g % 2), 2 (g % 2) + 1 at the pixel shifted by THAT tap
-  const unsigned lds0 = (unsigned)(size_t)smem;   // the asm reads take LDS byte addresses
+  const unsigned lds0 = lds0_();   // the asm reads take LDS byte addresses
   const unsigned a_f = lds0 + (unsigned)(QOFF_W + g * 2048 + li * 16);
   const unsigned a_c = lds0 + (unsigned)(QOFF_W + (g >> 1) * 8192 + (g & 1) * 4096 + li * 16);
   const unsigned b_f = lds0 + (unsigned)(QOFF_XF + g * QPPL + (wrow * QXW + li) * 16);
@@ -420,12 +537,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   int tile = blockIdx.x;
   if (tile >= a.ntiles) return;
   Tile cur = decode(tile);
-  setup_x(cur);
   unsigned P = 0;   // running phase number (mod 4 = ring slot)
-  {
+  if constexpr (FP32IN) {
+    // the first chunk's f16 image (pass 1 of its three pixels per thread), then its first pixel again for pass 2 (phase 0)
+    setup_f(cur);
+    const __amdgpu_buffer_rsrc_t s0 = srd_f(cur, 0);
+    static_for<0, 3>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      static_for<0, 16>([&](auto jc) __attribute__((always_inline)) { ld_step(s0, k, jc); });
+      static_for<0, 36>([&](auto sc_) __attribute__((always_inline)) { cv1_step(k, sc_); });
+    });
+    static_for<0, 16>([&](auto jc) __attribute__((always_inline)) { ld_step(s0, 0, jc); });
+  } else {
+    setup_x(cur);
     const __amdgpu_buffer_rsrc_t s0 = srd_xf(cur, 0);
 #pragma unroll
     for (int k = 0; k < QNTASK; ++k) dma_x(s0, xf_dst, k);
+  }
+  {
     request_w(std::integral_constant<int, 0>{}, cur.cob, 0, 0u);
     request_w(std::integral_constant<int, 1>{}, cur.cob, 0, 1u);
     request_w(std::integral_constant<int, 2>{}, cur.cob, 0, 2u);
@@ -456,8 +585,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
       const bool wrap = last_chunk && has_next_tile;
       const Tile& xt = wrap ? nxt : cur;
       const int xchunk = last_chunk ? (has_next_tile ? 0 : chunk) : chunk + 1;
-      const __amdgpu_buffer_rsrc_t s6 = srd_x6(cur, chunk);
-      __amdgpu_buffer_rsrc_t sf = s6;   // (set at phase 7)
+      const __amdgpu_buffer_rsrc_t s6 = FP32IN ? srd_f(cur, chunk) : srd_x6(cur, chunk);   // FP32IN: this chunk's planes (pass 2)
+      __amdgpu_buffer_rsrc_t sf = s6;   // the next chunk's source (set at phase 5 / 7)
       static_for<0, QNPH>([&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         constexpr int pn = (p + 1) % QNPH;
@@ -469,9 +598,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
         landed_a(0);
         landed_b(p & 1);
         const unsigned sb = ((P + p) & 3u) * QWSLOT, sbn = ((P + p + 1) & 3u) * QWSLOT;
-        if constexpr (p == 7) {
+        if constexpr (!FP32IN && p == 7) {
           if (wrap) setup_x(nxt);   // uniform; this chunk's FP6 image was requested in phases 0..4
           sf = srd_xf(xt, xchunk);
+        }
+        if constexpr (FP32IN && p == 5) {
+          if (wrap) setup_f(nxt);   // uniform; this chunk's last pass-2 loads went out in phase 2
+          sf = srd_f(xt, xchunk);
         }
         static_for<0, 4>([&](auto c2c) __attribute__((always_inline)) {
           constexpr int c2 = decltype(c2c)::value;
@@ -485,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
                 if constexpr (p + 3 < QNPH) request_w(std::integral_constant<int, p + 3>{}, cur.cob, chunk, (P + p + 3) & 3u);
                 else request_w(std::integral_constant<int, p + 3 - QNPH>{}, xt.cob, xchunk, (P + p + 3) & 3u);
               }
-              if constexpr (c2 == 1) {   // halo requests of this phase
+              if constexpr (c2 == 1 && !FP32IN) {   // halo requests of this phase
                 if constexpr (p <= 4) { dma_x(s6, x6_dst, 2 * p); dma_x(s6, x6_dst, 2 * p + 1); }
                 if constexpr (p == 8) { dma_x(sf, xf_dst, 0); dma_x(sf, xf_dst, 1); dma_x(sf, xf_dst, 2); }
                 if constexpr (p == 9) { dma_x(sf, xf_dst, 3); dma_x(sf, xf_dst, 4); dma_x(sf, xf_dst, 5); }
@@ -505,19 +638,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
                 landed_a((c2 + 1) & 1);
               }
             }
+            if constexpr (FP32IN) {
+              // staging step s = 16 c2 + mm of this phase (schedule in the file header): conversion steps 0..37, then the next
+              // pixel's loads in steps 40..55; phase 6 only loads
+              constexpr int st = 16 * c2 + mm;
+              constexpr int kcv = p == 0 || p == 8 ? 0 : (p == 2 || p == 10 ? 1 : 2);
+              if constexpr (p == 0 || p == 2 || p == 4) {
+                if constexpr (st < 38) cv2_step(kcv, std::integral_constant<int, st>{});
+              }
+              if constexpr (p == 8 || p == 10 || p == 12) {
+                if constexpr (st < 36) cv1_step(kcv, std::integral_constant<int, st>{});
+              }
+              if constexpr (st >= 40 && st < 56) {
+                if constexpr (p == 0) ld_step(s6, 1, std::integral_constant<int, st - 40>{});
+                if constexpr (p == 2) ld_step(s6, 2, std::integral_constant<int, st - 40>{});
+                if constexpr (p == 8) ld_step(sf, 1, std::integral_constant<int, st - 40>{});
+                if constexpr (p == 10) ld_step(sf, 2, std::integral_constant<int, st - 40>{});
+                if constexpr (p == 12) ld_step(sf, 0, std::integral_constant<int, st - 40>{});
+              }
+              if constexpr (p == 6 && st < 16) ld_step(sf, 0, std::integral_constant<int, st>{});
+              if constexpr (p == 0 || p == 2 || p == 4 || p == 6 || p == 8 || p == 10 || p == 12) __builtin_amdgcn_sched_barrier(0);
+            }
           });
         });
         Q16_PSTAMP(p, 2);
         // everything requested before this phase has landed (its own requests may be outstanding).  Behind a tile's last
         // phase: all of it -- the epilogue's stores come next in the queue, and a counted wait behind them would wait
         // for them too; the first phase of a tile therefore does not wait (its needs were met here).
+        constexpr int NREQ = q_nw(p) + (FP32IN ? ((p == 0 || p == 2 || p == 6 || p == 8 || p == 10 || p == 12) ? 32 : 0) : q_nh(p));
         if constexpr (p == QNPH - 1) {
           if (last_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else wait_vm<q_nw(p) + q_nh(p)>();
+          else wait_vm<NREQ>();
         } else if constexpr (p == 0) {
-          if (chunk != 0 || (EOVAE_Q16_SAFE & 1)) wait_vm<q_nw(p) + q_nh(p)>();
+          if (chunk != 0 || (EOVAE_Q16_SAFE & 1)) wait_vm<NREQ>();
         } else {
-          wait_vm<q_nw(p) + q_nh(p)>();
+          wait_vm<NREQ>();
         }
         Q16_PSTAMP(p, 3);
       });
@@ -557,12 +712,15 @@ extern "C" int eovae_debug_q16_stamps(void* dst, size_t bytes) {
 
 // (a.x6 is not looked at: eovae_conv3x3_f16c8_which() asks without pointers; the entry sets it for every packed == 2 call)
 bool eovae_c8_q16_eligible(const ConvCArgs& a) {
-  return eovae_opt(EOVAE_OPT_C8_Q16) != 0 && a.packed == 2 && a.Hout % 16 == 0 && (!a.gn_sums || a.gn_shift <= 6) &&
+  const int opt = eovae_opt(EOVAE_OPT_C8_Q16);   // 0: never, 1: MX record inputs, 2: fp32 inputs (data gradients) too
+  return opt != 0 && (a.packed == 2 || (a.packed == 0 && opt >= 2 && eovae_opt(EOVAE_OPT_C8_MX))) && a.Hout % 16 == 0 &&
+         (!a.gn_sums || a.gn_shift <= 6) && (size_t)a.Hin * a.Win * 32 * 4 < (1ull << 32) &&
          (size_t)a.Hin * a.Win * 16 < (1ull << 31) && (size_t)9 * a.nchunk * a.ncob * C8_WTILE < (1ull << 32);
 }
 
 // a: prepared by eovae_c8_w4_launch (tiles, ntiles, xcd_remap)
 void eovae_c8_q16_launch(const ConvCArgs& a, int n_cu, hipStream_t st) {
   const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(256);
-  hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel, grid, blk, 0, st, a);
+  if (a.packed == 2) hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel<false>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel<true>, grid, blk, 0, st, a);
 }

@@ -681,7 +681,7 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   const int nblk = ni == 2 ? 2 * n_cu : n_cu;
   const dim3 grid((unsigned)(a.ntiles < nblk ? a.ntiles : nblk)), blk(256);
   a.mx = a.packed == 2 ? 1 : 0;   // MX operand records (format 2): their FP6 plane is the only correction operand they carry
-  if (ni == 4 && a.mx && eovae_c8_q16_eligible(a)) {   // 16 x 16 MFMAs, all-DMA feed (conv_f16c8_q16.hip)
+  if (ni == 4 && (a.mx || a.packed == 0) && eovae_c8_q16_eligible(a)) {   // 16 x 16 MFMAs (conv_f16c8_q16.hip): MX records / fp32 inputs
     eovae_c8_q16_launch(a, n_cu, st);
     return;
   }

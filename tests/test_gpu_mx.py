@@ -33,10 +33,10 @@ def f16c8_mx():
         lib.eovae_set_option(k, v)
 
 
-@pytest.fixture(params=[1, 0], ids=['q16', 'q32'])
+@pytest.fixture(params=[2, 0], ids=['q16', 'q32'])
 def mfma_shape(request):
-    """The one-wave kernel's two forms on MX records (library option c8_q16): 1 = conv_f16c8_q16.hip (16 x 16 MFMAs, correction
-    product over tap pairs, all-DMA feed; the default), 0 = conv_f16c8_w4.hip's MX instantiation (32 x 32 MFMAs)."""
+    """The one-wave kernel's two forms (library option c8_q16): 2 = conv_f16c8_q16.hip (16 x 16 MFMAs, correction product over
+    tap pairs; MX records by DMA, fp32 inputs quantised in the kernel; the default), 0 = conv_f16c8_w4.hip (32 x 32 MFMAs)."""
     from eo_vae_amd import lib as L
     L.check(L.load().eovae_set_option(b'c8_q16', request.param), 'set_option')
     return request.param
@@ -152,6 +152,32 @@ def test_forward_on_records_equals_the_emulated_product(n, c, cout, h, w, mfma_s
     assert rel(y_mx, exact) < 5e-5         # the scheme against fp64
     assert rel(y_f8, exact) < 5e-5 and rel(y_mx, y_f8) < 5e-5
     assert rel(y_mx, y_f8) > 1e-8          # and the two forms really are different arithmetic
+
+
+@pytest.mark.parametrize('n,c,cout,h,w', [(2, 128, 64, 32, 64), (3, 128, 256, 48, 96), (16, 256, 128, 32, 32)])
+def test_data_gradient_equals_the_emulated_product(n, c, cout, h, w, mfma_shape):
+    """dX of a plain 3x3 layer.  conv_f16c8_q16.hip's fp32 path quantises dY in the kernel -- f16(dY 2^k) and the block-scaled
+    e2m3 images of dY 2^k and of its f16 residual, blocks of 32 output channels per pixel -- and multiplies with the data-gradient
+    pack's parts: the float64 sum of the same three products.  (conv_f16c8_w4.hip: fp8 correction product, checked against fp64.)"""
+    import math
+    from eo_vae_amd import ops
+    from oracle import mx_emul as M
+    torch.manual_seed(c + cout)
+    x = torch.randn(n, c, h, w, device='cuda')
+    wt = torch.randn(cout, c, 3, 3, device='cuda') / (c * 9) ** 0.5
+    dy = torch.randn(n, cout, h, w, device='cuda') * 3e-4 * torch.exp2(torch.randint(-3, 3, (1, cout, 1, 1), device='cuda').float())
+    set_opt(b'c8_w4', 1)
+    xg = x.clone().requires_grad_(True)
+    ops.conv2d(xg, wt, None, None, 'normal').backward(dy)
+    torch.cuda.synchronize()
+    dx = xg.grad
+    dyc, wc = dy.cpu(), wt.cpu()
+    exact = F.conv_transpose2d(dyc.double(), wc.double(), padding=1)
+    assert rel(dx, exact) < 5e-5
+    if mfma_shape:
+        s = 2.0 ** (13 - math.floor(math.log2(float(dyc.abs().max()))))       # the kernel's range pre-scale
+        want = M.split_product(dyc * s, wc, lambda a_, b_: F.conv_transpose2d(a_, b_, padding=1), 1, 0) / s
+        assert rel(dx, want) < 3e-6
 
 
 def test_resnet_block_with_and_without_mx():

@@ -118,7 +118,7 @@ def test_rows_mfma_shapes_agree(n, cin, cout, h, w, corr):
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
     keep = lib.eovae_get_option(b'c8_q16')
     try:
-        assert keep == 1
+        assert keep >= 1
         got = {}
         for v in (1, 0):
             L.check(lib.eovae_set_option(b'c8_q16', v), 'set_option')

@@ -8,6 +8,7 @@ import numpy as np, torch
 from eo_vae_amd import ops, lib as L
 cin, cout, hw = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (128, 128, 256)
 use_res = 'res' in sys.argv[4:]
+use_fp32 = 'fp32' in sys.argv[4:]   # the data-gradient form: fp32 input quantised in the kernel
 ops.CONV_PRECISION = 'f16c8'
 lib = L.load()
 lib.eovae_set_option(b'c8_w4', 1)
@@ -21,7 +22,11 @@ xrec = ops.group_norm_silu(x, torch.ones(cin, device='cuda'), torch.zeros(cin, d
 assert ops.packed_format(xrec) == 2
 wp = torch.empty(lib.eovae_conv3x3_f16c8_packed_bytes(cout, cin, 0), dtype=torch.uint8, device='cuda')
 L.check(lib.eovae_conv3x3_f16c8_pack(L.ptr(w), L.ptr(wp), cout, cin, 0, 1.0, L.stream()), 'pack')
+amax = ops.absmax_bits(x)
 for _ in range(30):
+    if use_fp32:
+        L.check(lib.eovae_conv3x3_f16c8_fwd(L.ptr(x), L.ptr(wp), None, None, L.ptr(y), L.ptr(amax), B, cin, hw, hw, cout, hw, hw, 0, 0, 0, None, 0, L.stream()), 'fwd')
+        continue
     L.check(lib.eovae_conv3x3_f16c8_fwd_mx(L.ptr(xrec), None, L.ptr(wp), None, L.ptr(res), L.ptr(y), None, B, cin, hw, hw, cout, hw, hw, 0, 0, 2,
                                            L.ptr(gns), 32, None, L.stream()), 'fwd')
 torch.cuda.synchronize()
