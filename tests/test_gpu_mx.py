@@ -239,3 +239,36 @@ def test_both_forward_kernels_read_mx_records(kernel, mfma_shape):
         yd = y.double().view(n, 32, -1)
         ref = torch.stack([yd.sum(-1), (yd * yd).sum(-1)], -1)
         assert (sums - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
+@pytest.mark.parametrize('n,c,cout,hw,res', [(16, 128, 128, 256, True), (16, 256, 512, 64, False), (4, 512, 256, 128, True)])
+def test_16x16_kernel_at_the_model_shapes(n, c, cout, hw, res):
+    """conv_f16c8_q16.hip at full layer shapes (several tiles per block, several co blocks per halo tile, residual and GroupNorm
+    sums): run to run bit-identical -- its waits are counted by hand, a race would show here -- and within summation order of
+    the 32 x 32 kernel on the same records (in practice the two are bit-identical: same products, same order inside the MFMAs)."""
+    from eo_vae_amd import ops
+    torch.manual_seed(hw + c)
+    x = torch.randn(n, c, hw, hw, device='cuda') + 0.1
+    gamma, beta = torch.randn(c, device='cuda'), torch.randn(c, device='cuda')
+    wt = torch.randn(cout, c, 3, 3, device='cuda') / (c * 9) ** 0.5
+    b = torch.randn(cout, device='cuda')
+    r = torch.randn(n, cout, hw, hw, device='cuda') if res else None
+    set_opt(b'c8_w4', 1)
+    with torch.no_grad():
+        a = ops.group_norm_silu(x, gamma, beta, packed=True, cout=cout)
+        assert ops.packed_format(a) == 2
+
+        def run(q16):
+            set_opt(b'c8_q16', q16)
+            y = ops.conv2d(a, wt, b, r, 'normal')
+            sums = ops.gn_sums_of(y, 32)
+            torch.cuda.synchronize()
+            return y, (sums.clone() if sums is not None else None)
+        y1, s1 = run(1)
+        for _ in range(5):
+            y2, s2 = run(1)
+            assert torch.equal(y1, y2)
+        y0, s0 = run(0)
+    assert rel(y1, y0) < 2e-6
+    if s1 is not None and s0 is not None:
+        assert (s1 - s0).abs().max() <= 2e-6 * s0.abs().max()
