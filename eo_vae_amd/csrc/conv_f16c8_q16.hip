@@ -714,7 +714,8 @@ extern "C" int eovae_debug_q16_stamps(void* dst, size_t bytes) {
 bool eovae_c8_q16_eligible(const ConvCArgs& a) {
   const int opt = eovae_opt(EOVAE_OPT_C8_Q16);   // 0: never, 1: MX record inputs, 2: fp32 inputs (data gradients) too
   return opt != 0 && (a.packed == 2 || (a.packed == 0 && opt >= 2 && eovae_opt(EOVAE_OPT_C8_MX))) && a.Hout % 16 == 0 &&
-         (!a.gn_sums || a.gn_shift <= 6) && (size_t)a.Hin * a.Win * 32 * 4 < (1ull << 32) &&
+         (!a.gn_sums || a.gn_shift <= 6) && (size_t)a.Hin * a.Win * 32 * 4 < (1ull << 31) &&   // (the fp32 path's out-of-range marker 2^31 must lie beyond a chunk's 32 planes)
+        
          (size_t)a.Hin * a.Win * 16 < (1ull << 31) && (size_t)9 * a.nchunk * a.ncob * C8_WTILE < (1ull << 32);
 }
 

@@ -163,7 +163,7 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
 // of (g & 1, g >> 1); D lane (li, g) = ci 16 nh + li, co 16 half + 4 g + q.
 template <int SP, bool CORR, bool Q16 = false>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) {
-  static_assert(!Q16 || (SP == 0 && !CORR), "Q16: the plain f16-only form");
+  static_assert(!Q16 || !CORR, "Q16: the f16-only forms");
   __shared__ __attribute__((aligned(16))) unsigned char dys[SP ? 4 * DYSLOT : NRING * DYSLOT];   // SP: 2 slots x 2 pixel planes
   // FOUR arrays for the LDS-DMA targets (X row s + 3 is requested in stage s; row s + 1 is already read at the end of
   // stage s): with one array and a computed slot offset the compiler cannot tell a DMA write from the fragment reads of
@@ -377,15 +377,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
 
   // Q16: A row li of co-half `half` (+ half * 16 P16), pixels 8 g ..; B as b16off with the k-group g and the channel half as an
   // immediate (+ nh * 2 XP16)
-  const int a16q = (32 * ct + li) * P16 + 16 * g;
-  const int b16q = (4 * cih + ((li & 3) >> 1)) * XP16 + (8 * g + (li >> 2)) * 16 + (li & 1) * 8;
+  const int a16q = pxw * DYSLOT + (32 * ct + li) * P16 + 16 * g;
+  const int b16q = (4 * cih + ((li & 3) >> 1)) * XP16 + (8 * g + (li >> 2)) * 16 + (li & 1) * 8 + pxw * 16;
 
   constexpr int NT = SP ? 8 : 9;   // SP: acc[4 ci-tile + 2 a + b]
   f32x16 acc[Q16 ? 1 : NT];
-  f32x4 acc4[Q16 ? 9 : 1][2][2];   // Q16: [tap][co half][ci half]
+  f32x4 acc4[Q16 ? NT : 1][2][2];   // Q16: [tap | SP tile][co half][ci half]
   if constexpr (Q16) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc4[t][(q >> 3) & 1][(q >> 2) & 1][q & 3] = 0.f;
   } else {
@@ -621,6 +621,66 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
     const unsigned char* dsl = dys + K * (2 * DYSLOT);
     unsigned char* dnx = dys + R1 * (2 * DYSLOT);
     const unsigned char* xsl = xslot_of(std::integral_constant<int, Q>{});
+    if constexpr (Q16) {
+      // 32 MFMAs of 16 cycles in the order of the 32 x 32 form: per sub-step (kx, ci-tile) the old row's four (co half x ci half)
+      // first, then the new row's; A fragments = co halves, B fragments = ci halves of the ci-tile
+      A16[K][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16q));
+      A16[K][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(dsl + a16q + 16 * P16));
+      static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+        constexpr int IT = decltype(itc)::value, kx = IT >> 1, ci = IT & 1;
+        constexpr int TK = 4 * ci + kx, TR = 4 * ci + 2 + kx;   // a = 0: the new row; a = 1: the row before it
+        const f16x8 b0 = nb0, b1 = nb1;
+        if constexpr (IT == 1) {
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + NDY + NX) : "memory");   // newer than dY(s + 1): X(s + 2), dY(s + 2), X(s + 3)
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C0{}, dnx);
+        }
+        if constexpr (IT == 2) {
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C2{}, dnx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool useR = !(SP == 2 && py == 1), useB = !(SP == 2 && kx == 1 && pxw == 1);
+        if (useR && useB) mfma16q(acc4[TR][0][0], A16[R1][0], b0);
+        if constexpr (IT == 0) {
+          __builtin_amdgcn_sched_barrier(0);   // nothing of the request block in front of the stage's first MFMA
+          if (!(EOVAE_ROWS_ABL & 2)) request_dy(PC{});
+        }
+        if (useR && useB) mfma16q(acc4[TR][0][1], A16[R1][0], b1);
+        if constexpr (IT == 0) {
+          if (!(EOVAE_ROWS_ABL & 2)) {
+            request_x(xslot_of(std::integral_constant<int, (Q + 3) % 4>{}));
+            save_dy();
+            step();
+          }
+        }
+        if (useR && useB) mfma16q(acc4[TR][1][0], A16[R1][1], b0);
+        if (useR && useB) mfma16q(acc4[TR][1][1], A16[R1][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (IT < 3) {
+          constexpr int nkx = (IT + 1) >> 1, nci = (IT + 1) & 1, NO = nci * 4 * XP16;
+          nb0 = rtr16(xsl + b16q + NO + nkx * 16, xsl + b16q + NO + (nkx + 4) * 16);
+          nb1 = rtr16(xsl + b16q + NO + 2 * XP16 + nkx * 16, xsl + b16q + NO + 2 * XP16 + (nkx + 4) * 16);
+        } else {   // the next stage's first B fragments
+          const unsigned char* xn = xslot_of(std::integral_constant<int, (Q + 1) % 4>{});
+          nb0 = rtr16(xn + b16q, xn + b16q + 4 * 16);
+          nb1 = rtr16(xn + b16q + 2 * XP16, xn + b16q + 2 * XP16 + 4 * 16);
+        }
+        if constexpr (IT == 1) {
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C1{}, dnx);
+        }
+        if constexpr (IT == 2) {
+          if (!(EOVAE_ROWS_ABL & 1)) conv_piece(PN{}, C3{}, dnx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (useB) mfma16q(acc4[TK][0][0], A16[K][0], b0);
+        if (useB) mfma16q(acc4[TK][0][1], A16[K][0], b1);
+        if (useB) mfma16q(acc4[TK][1][0], A16[K][1], b0);
+        if (useB) mfma16q(acc4[TK][1][1], A16[K][1], b1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + NX) : "memory");   // X(s + 2) has landed
+      if (!(EOVAE_ROWS_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      return;
+    }
     if constexpr (CORR) {
       const i32x4 l = *reinterpret_cast<const i32x4*>(dsl + a8off), u = *reinterpret_cast<const i32x4*>(dsl + a8off + 16);
       A8[K] = (i32x8)__builtin_shufflevector(l, u, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -766,17 +826,20 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_f16c8_rows_kernel(WgCArgs a) 
   }
   // this block's partial tile [tap][128 co][64 ci], folded in a fixed order by wgrad_fold_kernel
   // (SP: eight tiles per block [px][2 a + b][128 co][64 ci]; the wave holds [ci-tile][2 a + b] of its px)
-  if constexpr (Q16) {   // lane (li, g): ci = 32 cih + 16 nh + li, co = 32 ct + 16 half + 4 g + q
-    float* pq = a.part + ((size_t)slab * a.split + ysub) * 9 * (128 * 64) + (32 * ct + 4 * g) * 64 + 32 * cih + li;
+  if constexpr (Q16) {   // lane (li, g): ci = 32 (ci-tile) + 16 nh + li, co = 32 ct + 16 half + 4 g + q
+    float* pq = a.part + (((size_t)slab * a.split + ysub) * (SP ? 8 : 9) + (SP ? 4 * pxw : 0)) * (128 * 64) + (32 * ct + 4 * g) * 64 + 32 * cih + li;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            pq[(size_t)t * (128 * 64) + (16 * hf + q) * 64 + 16 * nh] = acc4[t][hf][nh][q] * dyinv;
+          for (int q = 0; q < 4; ++q) {
+            // (SP: tile 2 a + b = t & 3 of the wave's column parity, ci-tile t >> 2)
+            const size_t to = SP ? (size_t)(t & 3) * (128 * 64) + (t >> 2) * 32 : (size_t)t * (128 * 64);
+            pq[to + (16 * hf + q) * 64 + 16 * nh] = acc4[t][hf][nh][q] * dyinv;
+          }
     return;
   }
   float* pt = a.part + (((size_t)slab * a.split + ysub) * (SP ? 8 : 9) + (SP ? 4 * pxw : 0)) * (128 * 64) + cih * 32 + r;
@@ -986,6 +1049,8 @@ int eovae_conv3x3_f16c8_wgrad_up(const float* x, const float* dy, float* dw, flo
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
   if (eovae_opt(EOVAE_OPT_C8_WGRAD_CORR))
     hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<1, true>), dim3(nslab * a.split), dim3(512), 0, st, a);
+  else if (eovae_opt(EOVAE_OPT_C8_Q16))
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<1, false, true>), dim3(nslab * a.split), dim3(512), 0, st, a);
   else
     hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<1, false>), dim3(nslab * a.split), dim3(512), 0, st, a);
   hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)(a.ncib * a.ncob_ * 128)), dim3(576), 0, st, a.part, dw, Cout, Cin, a.ncib,
@@ -1032,6 +1097,8 @@ int eovae_conv3x3_f16c8_wgrad_down(const float* x, const float* dy, float* dw, c
   a.xcd_remap = (a.split % 8 == 0) ? 1 : 0;
   if (eovae_opt(EOVAE_OPT_C8_WGRAD_CORR))
     hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<2, true>), dim3(nslab * a.split), dim3(512), 0, st, a);
+  else if (eovae_opt(EOVAE_OPT_C8_Q16) == 3)   // (measured 0-3 % SLOWER than the 32 x 32 form on the stride-2 layers: opt-in only, tests)
+    hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<2, false, true>), dim3(nslab * a.split), dim3(512), 0, st, a);
   else
     hipLaunchKernelGGL((wgrad3x3_f16c8_rows_kernel<2, false>), dim3(nslab * a.split), dim3(512), 0, st, a);
   hipLaunchKernelGGL(wgrad_down_fold_kernel, dim3((unsigned)(a.ncib * a.ncob_ * 32)), dim3(576), 0, st, a.part, dw, Cout, Cin, a.ncib,
