@@ -132,6 +132,35 @@ def test_rows_mfma_shapes_agree(n, cin, cout, h, w, corr):
         ops.CONV_PRECISION = old
 
 
+@pytest.mark.parametrize('form', ['up', 'down'])
+def test_sub_pixel_forms_on_both_mfma_shapes(form, corr):
+    """The x2-upsample (16 x 16 x 32 by default) and stride-2 (32 x 32 x 16 by default; c8_q16 = 3 selects the other) weight
+    gradients: the two MFMA shapes multiply the same operands."""
+    if corr:
+        pytest.skip('the correction-product form has one MFMA shape')
+    import torch.nn.functional as F
+    from eo_vae_amd import ops, lib as L
+    lib = L.load()
+    n, cin, cout, h, w = 2, 128, 128, 16, 64
+    x = (hashed((n, cin, h, w), 341, 1.0) * 2.0).cuda()
+    wt = hashed((cout, cin, 3, 3), 342, 1.0 / (cin * 9) ** 0.5).cuda()
+    gy = hashed((n, cout, 2 * h, 2 * w) if form == 'up' else (n, cout, h // 2, w // 2), 343, 1e-3).cuda()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, 'f16c8'
+    keep = lib.eovae_get_option(b'c8_q16')
+    try:
+        got = {}
+        for v in (0, 3):
+            L.check(lib.eovae_set_option(b'c8_q16', v), 'set_option')
+            wg = wt.clone().requires_grad_(True)
+            ops.conv2d(x, wg, None, None, form).backward(gy)
+            torch.cuda.synchronize()
+            got[v] = wg.grad.clone()
+        assert float(got[0].abs().max()) > 0 and rel_err(got[3], got[0]) < 2e-6
+    finally:
+        lib.eovae_set_option(b'c8_q16', keep)
+        ops.CONV_PRECISION = old
+
+
 def test_rows_kernel_is_the_default_and_switchable():
     from eo_vae_amd import lib as L
     lib = L.load()
