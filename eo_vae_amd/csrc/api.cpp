@@ -33,6 +33,7 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
     {"c8_q16", "EOVAE_C8_Q16", 1},                 // 16 x 16 MFMAs where a kernel has that form (higher clock under load): 1 (default) record inputs
                                                    // and the plain weight gradient; 2 the fp32-input data gradients too (measured 0.88-0.92 x the
                                                    // 32 x 32 kernel: an experiment that stays tested); 0: the 32 x 32 forms
+    {"c8_dgrad_mx", "EOVAE_C8_DGRAD_MX", 1},       // the one-wave kernel quantises fp32 inputs (data gradients) to f16 + MX-FP6 itself; 0: f16 + fp8
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};

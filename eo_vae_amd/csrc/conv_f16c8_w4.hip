@@ -42,6 +42,17 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// mx6_quant (conv_f16c8_common.h) on values that already sit in two sixteen-register tuples (k = 0..15 | 16..31)
+__device__ __forceinline__ void mx6_quant16(const f32x16& a, const f32x16& b, float amax, i32x4& p0, i32x4& p1) {
+  typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+  const unsigned sb = mx6_scale_byte(amax);
+  const float div = __builtin_bit_cast(float, sb << 23);
+  u32x6 q;
+  asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(q) : "v"(a), "v"(b), "v"(div));
+  p0[0] = (int)q[0]; p0[1] = (int)q[1]; p0[2] = (int)q[2]; p0[3] = (int)q[3];
+  p1[0] = (int)q[4]; p1[1] = (int)q[5]; p1[2] = (int)sb; p1[3] = 0;
+}
+
 #ifndef EOVAE_W4_SGB
 #define EOVAE_W4_SGB 1   // scheduling-group pattern inside a co-tile group (experiment hook)
 #endif
@@ -80,7 +91,15 @@ __device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
 // 0..3][pixel][16 B], piece = wave) -- two 16-byte loads and two 16-byte LDS stores per task.
 template <bool PACKED, int NI, bool MX>
 __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
-  static_assert(!MX || PACKED, "MX: record input only (the fp32 staging path follows)");
+  // FQ (round 5, late): fp32 input WITH the MX-FP6 correction product -- the data gradients.  The block-scaled operands need
+  // the 32 channels of a pixel's block in ONE thread (block amax, v_cvt_scalef32_2xpk16_fp6_f32 takes 32 values), so the
+  // staging changes its shape: a thread takes halo pixels tid, tid + 256, tid + 512 with all 32 channels of the chunk
+  // (96 dword loads per chunk instead of 80, ~2/3 of the conversion VALU of the fp8 form: one f16 pack + one residual per
+  // value, two quantising instructions per pixel) and keeps, per pixel, 16 registers of f16 pairs until the f16 image is free
+  // (phases 9, 11, 15) and 16 of FP6 pieces until the FP6 image is (phase 17).  The load / convert / write schedule below keeps
+  // the live staging registers at the fp8 form's 80.
+  constexpr bool FQ = !PACKED && MX;
+  static_assert(!FQ || NI == 4, "FQ: 16-row tiles");
   constexpr int TH = 4 * NI, TW = 32, BM = 128, KC = 32;
   constexpr int XW = TW + 2, NPX = (TH + 2) * XW;          // 18 x 34 = 612 (10 x 34 = 340) halo pixels
   constexpr int IMG = 4 * NPX * 16;                         // one halo image: f16 [4 octets][pixel][8 ch] = 39168 B;
@@ -141,8 +160,30 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   float xr[NTASK][8];
   unsigned xoff[NTASK];
   unsigned xokm = 0;
+  // FQ staging state: the pixel in conversion (two sixteen-register tuples: the quantising instruction's operands), per task
+  // the f16 pairs and the four FP6 pieces, the LDS byte offset of the task's pixel in a plane (or the dummy area)
+  f32x16 fa[3], fb[3];
+  int fh[3][16];
+  i32x4 f6[3][4];
+  float fahi[3], falo[3];
+  const unsigned ftid16 = (unsigned)tid * 16u;          // pixel tid + 256 k sits at ftid16 + 4096 k of a plane
+  const bool fidle2 = tid >= NPX - 512;                 // the third task covers pixels 512..611: threads 0..99
   auto setup_x = [&](const Tile& t) __attribute__((always_inline)) {
     xokm = 0;
+    if constexpr (FQ) {
+      int th = tid;
+      asm volatile("" : "+v"(th));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int pix = th + 256 * k;
+        const int rr = (pix * 241) >> 13, cc = pix - XW * rr;   // pix / 34, exact below 1024
+        const int vy = t.oy0 + rr - 1, vx = t.ox0 + cc - 1;
+        const bool ok = (pix < NPX) & ((unsigned)vy < (unsigned)a.Hin) & ((unsigned)vx < (unsigned)a.Win);
+        xokm |= (ok ? 1u : 0u) << k;
+        xoff[k] = 4u * (unsigned)(ok ? rr * a.Win + cc : a.Win + 1);
+      }
+      return;
+    }
     int ln = lane;
     asm volatile("" : "+v"(ln));   // keeps the per-task index math out of the registers that live across the chunk loop
 #pragma unroll
@@ -163,7 +204,64 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     if (PACKED)
       return reinterpret_cast<const char*>(a.x) +
              (((long)t.n * (a.Cin / 8) + c0 / 8 + wave) * (long)in_plane + origin) * (long)UNIT;
+    if (FQ)   // all 32 channels of the chunk from every thread: channel j at + j planes
+      return reinterpret_cast<const char*>(a.x) + (((long)t.n * a.Cin + c0) * (long)in_plane + origin) * 4;
     return reinterpret_cast<const char*>(a.x) + (((long)t.n * a.Cin + c0 + 8 * wave) * (long)in_plane + origin) * 4;
+  };
+  // ---- FQ staging steps (each takes a task k and a quarter i = 0..3 = channel octet i of the chunk)
+  auto fq_load = [&](const char* xb, int k, int half, int i) __attribute__((always_inline)) {   // 4 channels: 16 half + 4 i ..
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = 4 * i + c;
+      const float v = *reinterpret_cast<const float*>(xb + (size_t)(16 * half + j) * in_plane * 4 + xoff[k]);
+      if (half == 0) fa[k][j] = v; else fb[k][j] = v;
+    }
+  };
+  // conversion A, quarter i: scale (validity folded in) and running |max| of 8 channels; behind the last quarter quant(x)
+  auto fq_conv_a = [&](int k, int i) __attribute__((always_inline)) {
+    const float sm = ((xokm >> k) & 1) ? xs : 0.f;
+    float m = i == 0 ? 0.f : fahi[k];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int j = 8 * i + c;
+      const float v = (j < 16 ? fa[k][j] : fb[k][j - 16]) * sm;
+      if (j < 16) fa[k][j] = v; else fb[k][j - 16] = v;
+      m = __builtin_fmaxf(m, __builtin_fabsf(v));
+    }
+    fahi[k] = m;
+    if (i == 3) mx6_quant16(fa[k], fb[k], m, f6[k][2], f6[k][3]);
+  };
+  // conversion B, quarter i: f16 pairs of 8 channels, residuals in place, their running |max|; behind the last quarter
+  // quant(residual)
+  auto fq_conv_b = [&](int k, int i) __attribute__((always_inline)) {
+    float m = i == 0 ? 0.f : falo[k];
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+      const int j = 8 * i + c;
+      const float v0 = j < 16 ? fa[k][j] : fb[k][j - 16], v1 = j < 16 ? fa[k][j + 1] : fb[k][j - 15];
+      int hh;
+      float l0, l1;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(v0), "v"(v1));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hh), "v"(v0));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hh), "v"(v1));
+      fh[k][j >> 1] = hh;
+      if (j < 16) { fa[k][j] = l0; fa[k][j + 1] = l1; } else { fb[k][j - 16] = l0; fb[k][j - 15] = l1; }
+      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(l0), __builtin_fabsf(l1)));
+    }
+    falo[k] = m;
+    if (i == 3) mx6_quant16(fa[k], fb[k], m, f6[k][0], f6[k][1]);
+  };
+  // writes: octet i of task k into the f16 image / piece i into the FP6 image (image [plane][pixel][16 B]; the third task's
+  // idle threads write into the dummy area: no branch in the phase sequence)
+  auto fq_write16 = [&](int k, int i) __attribute__((always_inline)) {
+    i32x4 w;
+    w[0] = fh[k][4 * i]; w[1] = fh[k][4 * i + 1]; w[2] = fh[k][4 * i + 2]; w[3] = fh[k][4 * i + 3];
+    const unsigned dst = (k == 2 && fidle2) ? (unsigned)(OFF_DUMMY + lane * 16) : (unsigned)(i * (NPX * 16) + k * 4096) + ftid16;
+    *reinterpret_cast<i32x4*>(smem + dst) = w;
+  };
+  auto fq_write8 = [&](int k, int i) __attribute__((always_inline)) {
+    const unsigned dst = (k == 2 && fidle2) ? (unsigned)(OFF_DUMMY + lane * 16) : (unsigned)(OFF_X8 + i * (NPX * 16) + k * 4096) + ftid16;
+    *reinterpret_cast<i32x4*>(smem + dst) = f6[k][i];
   };
   // MX: piece `wave` of the chunk's FP6 plane, 16 bytes per pixel (the same offsets as the F plane)
   auto x6base = [&](const Tile& t, int c0) __attribute__((always_inline)) {
@@ -493,9 +591,18 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     w_issue(0, wsrc(cur.cob, 0, 0));
     w_issue(1, wsrc(cur.cob, 0, 1));
     const char* xb = xbase(cur, 0);
-    const char* x6b = MX ? x6base(cur, 0) : nullptr;
+    const char* x6b = (MX && PACKED) ? x6base(cur, 0) : nullptr;
+    if constexpr (FQ) {
+      static_for<0, 3>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+          fq_load(xb, k, 0, decltype(ic)::value);
+          fq_load(xb, k, 1, decltype(ic)::value);
+        });
+      });
+    }
 #pragma unroll
-    for (int k = 0; k < NTASK; ++k) {
+    for (int k = 0; k < (FQ ? 0 : NTASK); ++k) {
       if (PACKED) {
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(xb + xoff[k]);
         const f32x4 q1 = MX ? *reinterpret_cast<const f32x4*>(x6b + xoff[k])
@@ -511,8 +618,19 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
     w_commit(1, 1);
     w_issue(0, wsrc(cur.cob, 0, 2));
     w_issue(1, wsrc(cur.cob, 0, 3));
+    if constexpr (FQ) {
+      static_for<0, 3>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { fq_conv_a(k, decltype(ic)::value); });
+        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { fq_conv_b(k, decltype(ic)::value); });
+        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+          fq_write16(k, decltype(ic)::value);
+          fq_write8(k, decltype(ic)::value);
+        });
+      });
+    }
 #pragma unroll
-    for (int k = 0; k < NTASK; ++k) {
+    for (int k = 0; k < (FQ ? 0 : NTASK); ++k) {
       if (!PACKED) { convert_half(k, 0); convert_half(k, 1); }
       write16(k);
       write8(k);
@@ -546,7 +664,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
       const int xchunk = last_chunk ? (has_next_tile ? 0 : chunk) : chunk + 1;
       if (wrap) setup_x(nxt);
       const char* xb = xbase(xt, xchunk * KC);
-      const char* x6b = MX ? x6base(xt, xchunk * KC) : nullptr;
+      const char* x6b = (MX && PACKED) ? x6base(xt, xchunk * KC) : nullptr;
       static_for<0, 18>([&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         constexpr int pn = (p + 1) % 18;
@@ -569,7 +687,22 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
           else read_a(PN{}, std::integral_constant<int, 0>{});
           if constexpr (i < NI) read_b(PN{}, ic);
           // staging slice of this group
-          if constexpr (PACKED) {
+          if constexpr (FQ) {
+            // task k: loads in phases (4, 5 | 6, 7 | 10, 11), conversion A / B in (7, 8 | 9, 10 | 13, 14), f16 pairs into the
+            // f16 image in (9 | 11 | 15), FP6 pieces of all three into the FP6 image in 17 -- quarter i of each in group i
+            if constexpr (p == 4 || p == 5) fq_load(xb, 0, p - 4, i);
+            if constexpr (p == 6 || p == 7) fq_load(xb, 1, p - 6, i);
+            if constexpr (p == 10 || p == 11) fq_load(xb, 2, p - 10, i);
+            if constexpr (p == 7) fq_conv_a(0, i);
+            if constexpr (p == 8) fq_conv_b(0, i);
+            if constexpr (p == 9) { fq_write16(0, i); fq_conv_a(1, i); }
+            if constexpr (p == 10) fq_conv_b(1, i);
+            if constexpr (p == 11) fq_write16(1, i);
+            if constexpr (p == 13) fq_conv_a(2, i);
+            if constexpr (p == 14) fq_conv_b(2, i);
+            if constexpr (p == 15) fq_write16(2, i);
+            if constexpr (p == 17) { fq_write8(0, i); fq_write8(1, i); fq_write8(2, i); }
+          } else if constexpr (PACKED) {
             // records: f16 halves of tasks 0..9 in phases 0, 1; [lo' | hi'] halves in phases 9, 10
             if constexpr (p == 0 || p == 1 || p == 9 || p == 10) {
               constexpr int TPP = (NTASK + 1) / 2;   // tasks per phase
@@ -594,12 +727,12 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
             }
             if constexpr (p >= 3 && 2 * (p - 3) + (i >> 1) < NTASK) convert_half(2 * (p - 3) + (i >> 1), i & 1);
           }
-          if constexpr (p == 8) {          // the f16 image is idle from here to phase 17's requests
+          if constexpr (p == 8 && !FQ) {   // the f16 image is idle from here to phase 17's requests
 #pragma unroll
             for (int k = 0; k < NTASK; ++k)
               if ((k & 3) == i) write16(k);
           }
-          if constexpr (p == 17) {         // the fp8 image is idle from here to the next chunk's phase 8
+          if constexpr (p == 17 && !FQ) {  // the fp8 image is idle from here to the next chunk's phase 8
 #pragma unroll
             for (int k = 0; k < NTASK; ++k)
               if ((k & 3) == i) write8(k);
@@ -691,6 +824,9 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   } else {
     if (a.mx) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, true>), grid, blk, 0, st, a);
     else if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, false>), grid, blk, 0, st, a);
+    // fp32 input (the data gradients): MX-FP6 correction product quantised in the kernel (library options c8_mx, c8_dgrad_mx)
+    else if (eovae_opt(EOVAE_OPT_C8_MX) && eovae_opt(EOVAE_OPT_C8_DGRAD_MX))
+      hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4, true>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4, false>), grid, blk, 0, st, a);
   }
 }

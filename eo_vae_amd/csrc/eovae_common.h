@@ -22,6 +22,7 @@ enum {
   EOVAE_OPT_C8_MX,            // correction product on block-scaled FP6 operands where the kernel and its inputs allow it (1); 0: fp8 everywhere
   EOVAE_OPT_C8_WGRAD_CORR,    // row-streaming weight gradients WITH the fp8 correction product (the r4 arithmetic): 1; 0 (default): f16 x f16 alone
   EOVAE_OPT_C8_Q16,           // 16 x 16 MFMA shape in the kernels that have that form (1): the chip holds a higher clock on it; 0: 32 x 32
+  EOVAE_OPT_C8_DGRAD_MX,      // fp32-input launches of the one-wave kernel (the data gradients) with the MX-FP6 correction product (1); 0: fp8
   EOVAE_OPT_COUNT
 };
 int eovae_opt(int id);

@@ -156,9 +156,10 @@ def test_forward_on_records_equals_the_emulated_product(n, c, cout, h, w, mfma_s
 
 @pytest.mark.parametrize('n,c,cout,h,w', [(2, 128, 64, 32, 64), (3, 128, 256, 48, 96), (16, 256, 128, 32, 32)])
 def test_data_gradient_equals_the_emulated_product(n, c, cout, h, w, mfma_shape):
-    """dX of a plain 3x3 layer.  conv_f16c8_q16.hip's fp32 path quantises dY in the kernel -- f16(dY 2^k) and the block-scaled
-    e2m3 images of dY 2^k and of its f16 residual, blocks of 32 output channels per pixel -- and multiplies with the data-gradient
-    pack's parts: the float64 sum of the same three products.  (conv_f16c8_w4.hip: fp8 correction product, checked against fp64.)"""
+    """dX of a plain 3x3 layer.  Both one-wave kernels quantise dY themselves -- f16(dY 2^k) and the block-scaled e2m3 images of
+    dY 2^k and of its f16 residual, blocks of 32 output channels per pixel -- and multiply with the data-gradient pack's parts:
+    the float64 sum of the same three products.  (conv_f16c8_w4.hip with c8_dgrad_mx = 0: fp8 correction product, checked
+    against fp64 only.)"""
     import math
     from eo_vae_amd import ops
     from oracle import mx_emul as M
@@ -174,10 +175,18 @@ def test_data_gradient_equals_the_emulated_product(n, c, cout, h, w, mfma_shape)
     dyc, wc = dy.cpu(), wt.cpu()
     exact = F.conv_transpose2d(dyc.double(), wc.double(), padding=1)
     assert rel(dx, exact) < 5e-5
-    if mfma_shape:
-        s = 2.0 ** (13 - math.floor(math.log2(float(dyc.abs().max()))))       # the kernel's range pre-scale
-        want = M.split_product(dyc * s, wc, lambda a_, b_: F.conv_transpose2d(a_, b_, padding=1), 1, 0) / s
-        assert rel(dx, want) < 3e-6
+    s = 2.0 ** (13 - math.floor(math.log2(float(dyc.abs().max()))))       # the kernel's range pre-scale
+    want = M.split_product(dyc * s, wc, lambda a_, b_: F.conv_transpose2d(a_, b_, padding=1), 1, 0) / s
+    assert rel(dx, want) < 3e-6
+    if not mfma_shape:      # ... and the fp8 form is still there behind the same call
+        set_opt(b'c8_dgrad_mx', 0)
+        try:
+            xg2 = x.clone().requires_grad_(True)
+            ops.conv2d(xg2, wt, None, None, 'normal').backward(dy)
+            torch.cuda.synchronize()
+            assert rel(xg2.grad, exact) < 5e-5 and 1e-8 < rel(xg2.grad, dx) < 5e-5
+        finally:
+            set_opt(b'c8_dgrad_mx', 1)
 
 
 def test_resnet_block_with_and_without_mx():
