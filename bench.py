@@ -480,19 +480,23 @@ def main():
         elif prec == 'f16c8':
             peak, dtype = PEAK_BF16_MFMA, 'f16c8'
             kname = {1: 'conv3x3_f16c8_w4_kernel (plain 3x3 layers, one wave per SIMD, 4x4 blocks of 32x32 MFMAs: the data gradients '
-                        '(fp32 inputs converted in the kernel, fp8 correction product) and the forward of layers without MX records)',
+                        '(fp32 inputs quantised in the kernel to f16 + MX-FP6; fp8 with c8_dgrad_mx = 0) and the forward of layers '
+                        'without MX records)',
                      2: 'conv3x3_f16c8_q16_kernel (plain 3x3 layers on MX operand records -- the forward: one wave per SIMD, 8x8 '
                         'blocks of 16x16 MFMAs, MX-FP6 correction product over tap pairs, halo and weights by LDS-DMA)'
                      }.get(dom, 'conv3x3_f16c8_kernel (3x3 conv fwd + data-grad, f16 product + one fp8 correction product)')
             lib_ = ops.L.load()
             mx_on, wcorr = lib_.eovae_get_option(b'c8_mx') != 0, lib_.eovae_get_option(b'c8_wgrad_corr') != 0
+            dgrad_mx = mx_on and lib_.eovae_get_option(b'c8_dgrad_mx') != 0
             path = ('f16c8 implicit GEMM: x*w = f16(x)*f16(w) + ONE K-concatenated block-scaled correction product '
                     '[x_lo|x_hi].[w_hi|w_lo], fp32 accumulate (~1e-5 per product), on v_mfma_f32_32x32x16_f16 / '
                     'v_mfma_scale_f32_32x32x64_f8f6f4 or -- forward on MX records, plain weight gradients -- on the 16x16 forms '
                     '(v_mfma_f32_16x16x32_f16 / v_mfma_scale_f32_16x16x128_f8f6f4 over tap pairs: the chip holds a higher clock on them): '
                     + ('MX-FP6 (e2m3, per-32-channel E8M0 scales; 1.64 MFMA units per product) in the forward of the layers '
                        'GroupNorm feeds with MX operand records, ' if mx_on else '')
-                    + 'fp8 (e5m2 / e4m3; 2 units) in the data gradient and on fp32 inputs; weight gradients: '
+                    + ('and -- quantised inside the one-wave kernel, a thread = a pixel x 32 channels -- in their data gradients; fp8 (e5m2 / '
+                       'e4m3; 2 units) in the 8-wave kernel\'s fp32-input forms; weight gradients: ' if dgrad_mx else
+                       'fp8 (e5m2 / e4m3; 2 units) in the data gradient and on fp32 inputs; weight gradients: ')
                     + ('f16 product + fp8 correction (2 units)' if wcorr else
                        'f16(dY)*f16(X) alone (1 unit: a leaf of the computation, its rounding does not compound)')
                     + '; 1x1 convolutions and attention stay split-bf16 (3 units)')
@@ -536,7 +540,7 @@ def main():
             'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),
             # f16c8: forward = half of the conv flops, ~0.86 of it (the plain layers behind a GroupNorm) on the MX-FP6 form
             'ceiling': ceiling(timer.totals()[1] / args.steps, wtimer.totals()[1] / args.steps, args.batch, ips / world,
-                               ((2.0 - 0.5 * 0.86 * (2.0 - 1.64) if mx_on else 2.0) if prec == 'f16c8' else
+                               ((2.0 - (1.0 if dgrad_mx else 0.5) * 0.86 * (2.0 - 1.64) if mx_on else 2.0) if prec == 'f16c8' else
                                 (3.0 if prec == 'bf16x3' else (16.0 if prec == 'f32' else 1.0))), clock_ghz,
                                (2.0 if wcorr else 1.0) if prec == 'f16c8' else None)
             if args.workload != 'cfg5' else None,
