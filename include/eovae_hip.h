@@ -120,7 +120,9 @@ int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, c
                             int Hout, int Wout, int mode, int subpix, int xpacked, double* gn_sums, int gn_groups, unsigned* out_amax,
                             void* stream);
 /* which kernel the call above launches for these arguments: 1 = conv3x3_f16c8_w4_kernel (csrc/conv_f16c8_w4.hip: one wave
- * per SIMD, 4 x 4 register blocking, 16-row tiles -- plain layers that give every CU two tiles), 0 =
+ * per SIMD, 4 x 4 register blocking, 16-row tiles -- plain layers that give every CU two tiles; fp32 inputs are quantised
+ * to f16 + MX-FP6 in the kernel: library option c8_dgrad_mx), 2 = conv3x3_f16c8_q16_kernel (csrc/conv_f16c8_q16.hip: the
+ * same walk on 16 x 16 MFMAs, every byte by LDS-DMA -- those layers on MX operand records; library option c8_q16), 0 =
  * conv3x3_f16c8_kernel (8 waves, 8-row tiles: sub-pixel / space-to-depth forms, small grids).  No launch. */
 int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
                               int xpacked);
