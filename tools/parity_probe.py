@@ -25,11 +25,14 @@ prod = prod.cuda()
 del oracle
 ops.CONV_PRECISION = 'f16c8'
 for case in cases:
-    for mx, corr in ((0, 1), (1, 1), (0, 0), (1, 0)):
+    # (mx, wgrad_corr, dgrad_mx, q16): r4 arithmetic ... the default (MX forward and data gradient, 16 x 16 kernels)
+    for mx, corr, dmx, q16 in ((0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (1, 0, 0, 1), (1, 0, 1, 1)):
         lib.eovae_set_option(b'c8_mx', mx)
         lib.eovae_set_option(b'c8_wgrad_corr', corr)
+        lib.eovae_set_option(b'c8_dgrad_mx', dmx)
+        lib.eovae_set_option(b'c8_q16', q16)
         prod.load_state_dict(state)      # a train-mode forward moves the latent BatchNorm's running statistics
         e = P.full_step_errors(prod, case=case)
-        print(f"{case} mx={mx} wgrad_corr={corr}: loss {e['loss_rel_err']:.2e} recon {e['recon_max_rel_err']:.2e} "
+        print(f"{case} mx={mx} wgrad_corr={corr} dgrad_mx={dmx} q16={q16}: loss {e['loss_rel_err']:.2e} recon {e['recon_max_rel_err']:.2e} "
               f"grad norm {e['grad_norm_rel_err']:.2e} worst tensor norm {e['grad_worst_norm_rel_err']:.2e} "
               f"worst sample {e['grad_worst_sample_rel_err']:.2e} ({e['grad_worst_tensor']})", flush=True)
