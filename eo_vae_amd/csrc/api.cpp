@@ -34,6 +34,7 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
                                                    // and the plain weight gradient; 2 the fp32-input data gradients too (measured 0.88-0.92 x the
                                                    // 32 x 32 kernel: an experiment that stays tested); 0: the 32 x 32 forms
     {"c8_dgrad_mx", "EOVAE_C8_DGRAD_MX", 1},       // the one-wave kernel quantises fp32 inputs (data gradients) to f16 + MX-FP6 itself; 0: f16 + fp8
+    {"c8_up_q16", "EOVAE_C8_UP_Q16", 1},           // x2-upsample forward: MX records of x + conv_f16c8_q16up.hip (both column parities per wave); 0: 8-wave sub-pixel mode
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -75,6 +76,6 @@ int eovae_get_option(const char* name) {
   eovae_set_error("eovae_get_option: unknown option '%s'", name ? name : "(null)");
   return EOVAE_ERR_ARG;
 }
-int eovae_abi_version(void) { return 11; }  // 11: MX-FP6 correction product (eovae_gn_silu_fwd_packed_mx, eovae_conv3x3_f16c8_fwd_mx, 24 KiB weight tiles); 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option; 10: eovae_gen_* (weight generators)
+int eovae_abi_version(void) { return 12; }  // 12: eovae_conv3x3_f16c8_up_mx, eovae_records_mx_from_f32 (x2-upsample forward on MX records); 11: MX-FP6 correction product (eovae_gn_silu_fwd_packed_mx, eovae_conv3x3_f16c8_fwd_mx, 24 KiB weight tiles); 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option; 10: eovae_gen_* (weight generators)
 const char* eovae_target_arch(void) { return "gfx950"; }
 }

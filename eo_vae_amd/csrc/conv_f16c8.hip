@@ -1914,10 +1914,15 @@ int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Ho
   ConvCArgs a;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = Hout; a.Wout = Wout; a.mode = mode;
   a.packed = xpacked; a.x6 = nullptr; a.mx = 0; a.gn_sums = nullptr; a.gn_shift = 0;
+  // a forward call on records carries the following GroupNorm(32)'s sums (ops.GN_GROUPS_HINT): the group size the launcher sees
+  if (xpacked && Cout % 32 == 0) {
+    a.gn_sums = reinterpret_cast<double*>(1);
+    while ((1 << a.gn_shift) < Cout / 32) ++a.gn_shift;
+  }
   a.nchunk = Cin / 32; a.ncob = cdiv(Cout, 128);
   const int n_cu = c8_n_cu();
   if (!(n_cu > 0 && subpix == 0 && eovae_c8_w4_eligible(a, subpix, n_cu))) return 0;
-  return (eovae_opt(EOVAE_OPT_C8_W4_NI) != 2 && eovae_c8_q16_eligible(a)) ? 2 : 1;
+  return eovae_c8_one_wave_kind(a, n_cu);   // the launcher's own decision function
 }
 
 // 3x3 stride-1 conv / data gradient with f16c8 operands.  Arguments as eovae_conv3x3_bf16_fwd; the GEMM K

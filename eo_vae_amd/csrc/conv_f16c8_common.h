@@ -112,6 +112,7 @@ __device__ __forceinline__ int expo_of_bits(unsigned bits) {
 // (plain 3x3 form, full 16 x 32 tiles only); returns false when the layer does not qualify.
 bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu);
 void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st);
+int eovae_c8_one_wave_kind(ConvCArgs a, int n_cu);
 // conv_f16c8_q16.hip: the same tile walk on 16 x 16 MFMAs with an all-DMA feed, for MX operand records (library option c8_q16)
 bool eovae_c8_q16_eligible(const ConvCArgs& a);
 void eovae_c8_q16_launch(const ConvCArgs& a, int n_cu, hipStream_t st);

@@ -52,20 +52,9 @@
 #include <type_traits>
 
 #include "conv_f16c8_common.h"
+#include "conv_f16c8_q16_asm.h"
 
 namespace {
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x6 __attribute__((ext_vector_type(6)));
-using lds_ptr = __attribute__((address_space(3))) void*;
 
 constexpr int QBM = 128, QXW = 34, QNPX = 18 * QXW, QNTASK = 10;
 constexpr int QPPL = 640 * 16;                 // one octet's / piece's plane of the halo images: 640 pixels (612 + DMA padding)
@@ -102,21 +91,6 @@ __device__ unsigned long long q16_stamps[4 * 32 * 4];
 #define Q16_STAMP(id) do {} while (0)
 #define Q16_PSTAMP(p, id) do {} while (0)
 #endif
-#ifndef EOVAE_Q16_ABL
-#define EOVAE_Q16_ABL 0   // timing-only experiments (WRONG results): 1 no s_nop in front of the correction MFMAs, 2 no output stores,
-                          // 4 every tile of a block stored to the same place (the output stays in the caches)
-#endif
-typedef int i32x3 __attribute__((ext_vector_type(3)));
-template <int OFF>
-__device__ __forceinline__ void rd96(i32x3& d, unsigned a) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds offset");
-  asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void wr128(unsigned a, const i32x4& d) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds offset");
-  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(d), "n"(OFF) : "memory");
-}
 // mx6_quant (conv_f16c8_common.h) on values that already sit in two sixteen-register tuples (k = 0..15 | 16..31)
 __device__ __forceinline__ void mx6_quant16(const f32x16& a, const f32x16& b, float amax, i32x4& p0, i32x4& p1) {
   typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
@@ -126,32 +100,6 @@ __device__ __forceinline__ void mx6_quant16(const f32x16& a, const f32x16& b, fl
   asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(q) : "v"(a), "v"(b), "v"(div));
   p0[0] = (int)q[0]; p0[1] = (int)q[1]; p0[2] = (int)q[2]; p0[3] = (int)q[3];
   p1[0] = (int)q[4]; p1[1] = (int)q[5]; p1[2] = (int)sb; p1[3] = 0;
-}
-template <int OFF>
-__device__ __forceinline__ void rd128(i32x4& d, unsigned a) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds offset");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
-}
-__device__ __forceinline__ void mfma_f(f32x4& c, const i32x4& a, const i32x4& b) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-// TAIL: the last MFMAs of a chunk carry their own s_nop 15 -- behind the chunk loop the compiler reads / moves accumulators
-// (epilogue), and it knows no MFMA hazard for registers an asm statement wrote
-template <bool TAIL = false>
-__device__ __forceinline__ void mfma_c(f32x4& c, const i32x6& a, const i32x6& b, int sa, int sb) {
-  if constexpr (TAIL) {
-    asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\ts_nop 15"
-                 : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
-    return;
-  }
-  // s_nop 1: the operands' last two dwords reach their six-register tuples through v_mov copies, and an MFMA may not read a
-  // register a VALU instruction wrote less than two wait states earlier -- a hazard hipcc covers for its own MFMAs only
-  if (EOVAE_Q16_ABL & 1)
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
-                 : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
-  else
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
-               : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
 // placement of a pair's side work: index of the MFMA (0..15) it follows
 #ifndef EOVAE_Q16_MM_DMA
@@ -166,18 +114,6 @@ __device__ __forceinline__ void mfma_c(f32x4& c, const i32x6& a, const i32x6& b,
 #ifndef EOVAE_Q16_MM_B1
 #define EOVAE_Q16_MM_B1 11
 #endif
-#ifndef EOVAE_Q16_SAFE
-#define EOVAE_Q16_SAFE 0   // bisection: 1 every counted vmcnt wait becomes vmcnt(0), 2 every counted lgkmcnt wait lgkmcnt(0)
-#endif
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((EOVAE_Q16_SAFE & 2) ? 0 : N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EOVAE_Q16_SAFE & 1) ? 0 : (N < 63 ? N : 63)) : "memory");
-}
-
 template <bool FP32IN>
 __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) {
   // the DMA targets / fragment sources; the GroupNorm cells live in an array of their own so that the compiler does not
@@ -667,8 +603,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
         // for them too; the first phase of a tile therefore does not wait (its needs were met here).
         constexpr int NREQ = q_nw(p) + (FP32IN ? ((p == 0 || p == 2 || p == 6 || p == 8 || p == 10 || p == 12) ? 32 : 0) : q_nh(p));
         if constexpr (p == QNPH - 1) {
-          if (last_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else wait_vm<NREQ>();
+          if (last_chunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The next phase-0 fragments (Ar[0], Ah[0], Br[0], Bh[0]) were requested by asm reads in this phase.  To the
+            // compiler they exist already, so the compiler-scheduled epilogue behind this loop may copy or spill those
+            // registers while the LDS return is still pending (hazard (i) of the file header; it would hit co-tile pair 0).
+            // Land them here: a few hundred cycles against a ~100 k-cycle tile.
+            wait_lgkm<0>();
+            landed_a(0);
+            landed_b(0);
+          } else wait_vm<NREQ>();
         } else if constexpr (p == 0) {
           if (chunk != 0 || (EOVAE_Q16_SAFE & 1)) wait_vm<NREQ>();
         } else {
@@ -715,7 +659,8 @@ bool eovae_c8_q16_eligible(const ConvCArgs& a) {
   const int opt = eovae_opt(EOVAE_OPT_C8_Q16);   // 0: never, 1: MX record inputs, 2: fp32 inputs (data gradients) too
   return opt != 0 && (a.packed == 2 || (a.packed == 0 && opt >= 2 && eovae_opt(EOVAE_OPT_C8_MX))) && a.Hout % 16 == 0 &&
          (!a.gn_sums || a.gn_shift <= 6) && (size_t)a.Hin * a.Win * 32 * 4 < (1ull << 31) &&   // (the fp32 path's out-of-range marker 2^31 must lie beyond a chunk's 32 planes)
-        
+         // the epilogue's 32-bit byte arithmetic: a co-block's span of y (descriptor range) and 7 * tile16 + lot stay below 2^31
+         (size_t)QBM * a.Hout * a.Wout * 4 < (1ull << 31) &&
          (size_t)a.Hin * a.Win * 16 < (1ull << 31) && (size_t)9 * a.nchunk * a.ncob * C8_WTILE < (1ull << 32);
 }
 

@@ -801,6 +801,15 @@ bool eovae_c8_w4_eligible(const ConvCArgs& a, int subpix, int n_cu) {
   return tiles >= (ni == 2 ? 4LL : 2LL) * n_cu;   // fewer tiles than two per block leave CUs idle: the 8-wave kernel takes those
 }
 
+// The ONE decision between the two one-wave-per-SIMD kernels for an eligible call (eovae_c8_w4_eligible): 2 = conv_f16c8_q16.hip
+// (16 x 16 MFMAs: MX records, or fp32 inputs under option c8_q16 = 2), 1 = this file's kernel.  Used by the launcher below and
+// by eovae_conv3x3_f16c8_which(), so that time attributed to a kernel (bench.py) is the kernel that ran.
+int eovae_c8_one_wave_kind(ConvCArgs a, int n_cu) {
+  const int ni = w4_rows_per_wave(a, n_cu);
+  a.mx = a.packed == 2 ? 1 : 0;
+  return (ni == 4 && (a.mx || a.packed == 0) && eovae_c8_q16_eligible(a)) ? 2 : 1;
+}
+
 void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   const int ni = w4_rows_per_wave(a, n_cu);
   a.tiles_x = a.Wout / 32;
@@ -814,7 +823,7 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
   const int nblk = ni == 2 ? 2 * n_cu : n_cu;
   const dim3 grid((unsigned)(a.ntiles < nblk ? a.ntiles : nblk)), blk(256);
   a.mx = a.packed == 2 ? 1 : 0;   // MX operand records (format 2): their FP6 plane is the only correction operand they carry
-  if (ni == 4 && (a.mx || a.packed == 0) && eovae_c8_q16_eligible(a)) {   // 16 x 16 MFMAs (conv_f16c8_q16.hip): MX records / fp32 inputs
+  if (eovae_c8_one_wave_kind(a, n_cu) == 2) {   // 16 x 16 MFMAs (conv_f16c8_q16.hip): MX records / fp32 inputs
     eovae_c8_q16_launch(a, n_cu, st);
     return;
   }

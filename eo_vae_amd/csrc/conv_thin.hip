@@ -204,6 +204,7 @@ int eovae_conv3x3_thin_wgrad_eligible(int N, int Cin, int H, int W, int Cout, in
 int eovae_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int Cin, int H, int W,
                              int Cout, int xpacked, void* ws, void* stream) {
   EOVAE_CHECK_ARG(x && dy && dw && ws, "conv3x3_thin_wgrad: null pointer");
+  EOVAE_CHECK_ARG(xpacked == 0 || xpacked == 1, "conv3x3_thin_wgrad: xpacked %d (0 fp32, 1 operand records; MX records are not read here)", xpacked);
   EOVAE_CHECK_ARG(eovae_conv3x3_thin_wgrad_eligible(N, Cin, H, W, Cout, xpacked),
                   "conv3x3_thin_wgrad: shape not supported (N %d Cin %d H %d W %d Cout %d xpacked %d)", N, Cin, H, W, Cout,
                   xpacked);
@@ -360,6 +361,7 @@ int eovae_conv3x3_thin_fwd_eligible(int N, int Cin, int H, int W, int Cout) {
 int eovae_conv3x3_thin_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                            int Cout, int xpacked, void* stream) {
   EOVAE_CHECK_ARG(x && w && y, "conv3x3_thin_fwd: null pointer");
+  EOVAE_CHECK_ARG(xpacked == 0 || xpacked == 1, "conv3x3_thin_fwd: xpacked %d (0 fp32, 1 operand records; MX records are not read here)", xpacked);
   EOVAE_CHECK_ARG(eovae_conv3x3_thin_fwd_eligible(N, Cin, H, W, Cout),
                   "conv3x3_thin_fwd: shape not supported (N %d Cin %d H %d W %d Cout %d)", N, Cin, H, W, Cout);
   hipStream_t st = (hipStream_t)stream;

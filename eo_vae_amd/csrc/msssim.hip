@@ -41,7 +41,7 @@ template <bool ADJ>
 __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ y, int C, int H,
                                                         int W, Taps taps, float c1, float c2,
-                                                        double* __restrict__ sums,      // [B][2]
+                                                        float* __restrict__ parts,      // ADJ = false: [plane][tile][2] block sums
                                                         const float* __restrict__ coef,  // [B]
                                                         const float* __restrict__ gout, int use_ssim,
                                                         float* __restrict__ a1, float* __restrict__ a2,
@@ -98,8 +98,11 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
     if ((tid & 63) == 0) { red[tid >> 6] = v0; red[4 + (tid >> 6)] = v1; }
     __syncthreads();
     if (tid == 0) {
-      atomicAdd(&sums[2 * b], (double)((red[0] + red[1]) + (red[2] + red[3])));
-      atomicAdd(&sums[2 * b + 1], (double)((red[4] + red[5]) + (red[6] + red[7])));
+      // one partial pair per block, folded per image in a fixed order by ssim_fold_kernel (round 6: fp64 atomics of 49 k
+      // blocks on 2 B addresses serialised -- the scale-0 launch ran at 125 GB/s, profiles/r06a_cfg3_kernels.json)
+      float* o = parts + ((size_t)plane * gridDim.x + blockIdx.x) * 2;
+      o[0] = (red[0] + red[1]) + (red[2] + red[3]);
+      o[1] = (red[4] + red[5]) + (red[6] + red[7]);
     }
   } else if (inimg) {
     float o1 = 0.f, o2 = 0.f, o3 = 0.f;
@@ -174,6 +177,27 @@ __global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict_
   dx[o] = v;
 }
 
+// sums[(s B + b)][v] = sum over image b's C planes x tiles of the block partials of scale s, fp64, fixed order
+// (bit-reproducible).  grid (B, S), 256 threads.
+struct FoldArgs { size_t off[MAXS]; int tiles[MAXS]; };
+__global__ __launch_bounds__(256) void ssim_fold_kernel(const float* __restrict__ parts, double* __restrict__ sums, int B, int C,
+                                                        FoldArgs fa) {
+  const int b = blockIdx.x, s = blockIdx.y;
+  const size_t n = (size_t)C * fa.tiles[s];
+  const float* p = parts + fa.off[s] + (size_t)b * n * 2;
+  double a0 = 0, a1 = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) { a0 += (double)p[2 * i]; a1 += (double)p[2 * i + 1]; }
+  a0 = wave_sum_d(a0);
+  a1 = wave_sum_d(a1);
+  __shared__ double red[8];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a0; red[4 + (threadIdx.x >> 6)] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sums[((size_t)s * B + b) * 2] = (red[0] + red[1]) + (red[2] + red[3]);
+    sums[((size_t)s * B + b) * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+
 // per-image factors -> value and the backward coefficients d(out)/d(mean_s,b) / count_s
 __global__ void msssim_finalize_kernel(const double* __restrict__ sums, float* __restrict__ coef,
                                        float* __restrict__ out, int B, int S,
@@ -204,6 +228,7 @@ __global__ void msssim_finalize_kernel(const double* __restrict__ sums, float* _
 struct Layout {
   size_t px[MAXS], py[MAXS];  // float offsets of pyramid levels >= 1
   size_t sums, coef, amaps, dlev0, dlev1, total_bytes;
+  size_t parts;   // (the forward's block partials live in the adjoint-map region: the backward overwrites it after the fold)
   int hs[MAXS], wsz[MAXS];
 };
 
@@ -226,6 +251,7 @@ Layout make_layout(int B, int C, int H, int W, int S) {
   L.coef = bytes; bytes += (size_t)S * B * sizeof(float);
   bytes = (bytes + 15) / 16 * 16;
   L.amaps = bytes; bytes += 3 * (size_t)B * C * H * W * sizeof(float);
+  L.parts = L.amaps;   // <= 2 floats per 16 x 16 tile and scale: far below the three full-resolution maps
   size_t lev1 = (size_t)B * C * (H / 2) * (W / 2) * sizeof(float);
   L.dlev0 = bytes; bytes += lev1;
   L.dlev1 = bytes; bytes += lev1;
@@ -268,7 +294,14 @@ int eovae_msssim_fwd(const float* pred, const float* target, float* out, int B, 
   float* fbase = (float*)ws;
   double* sums = (double*)(base + L.sums);
   float* coef = (float*)(base + L.coef);
-  hipMemsetAsync(sums, 0, (size_t)scales * B * 2 * sizeof(double), st);
+  float* parts = (float*)(base + L.parts);
+  FoldArgs fa;
+  size_t poff = 0;
+  for (int s = 0; s < MAXS; ++s) {
+    fa.tiles[s] = s < scales ? cdiv(L.hs[s], TS) * cdiv(L.wsz[s], TS) : 0;
+    fa.off[s] = poff;
+    poff += (size_t)B * C * fa.tiles[s] * 2;
+  }
   Counts counts;
   for (int s = 0; s < MAXS; ++s)
     counts.c[s] = s < scales ? (double)C * (L.hs[s] - 2 * R) * (L.wsz[s] - 2 * R) : 1.0;
@@ -280,7 +313,7 @@ int eovae_msssim_fwd(const float* pred, const float* target, float* out, int B, 
     const int h = L.hs[s], w = L.wsz[s];
     dim3 grid(cdiv(h, TS) * cdiv(w, TS), B * C);
     hipLaunchKernelGGL(ssim_tile_kernel<false>, grid, dim3(256), 0, st, x, y, C, h, w, taps, c1, c2,
-                       sums + (size_t)s * B * 2, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+                       parts + fa.off[s], nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     if (s + 1 < scales) {
       float* nx = fbase + L.px[s + 1];
       float* ny = fbase + L.py[s + 1];
@@ -292,6 +325,7 @@ int eovae_msssim_fwd(const float* pred, const float* target, float* out, int B, 
       x = nx; y = ny;
     }
   }
+  hipLaunchKernelGGL(ssim_fold_kernel, dim3(B, scales), dim3(256), 0, st, parts, sums, B, C, fa);
   hipLaunchKernelGGL(msssim_finalize_kernel, dim3(1), dim3(64), 0, st, sums, coef, out, B, scales,
                      betas, counts);
   EOVAE_CHECK_LAUNCH("eovae_msssim_fwd");

@@ -50,6 +50,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const float* __restrict__ clip_coef,
                                                    float grad_scale, float decay) {
   const float cs = (clip_coef ? clip_coef[1] : 1.f) * grad_scale;
+  // Fault containment: a non-finite gradient norm -- a GroupNorm-backward time-out poisons dgamma / dbeta with NaN,
+  // and under data parallelism the all-reduce hands the same NaN to every rank -- leaves parameters and moments untouched.
+  // Every rank takes the same branch (same averaged gradient, same norm), so replicas stay identical and a checkpoint written
+  // before the host raises (ops.raise_on_gn_backward_timeouts, up to three steps later) is clean.  The reference would
+  // write NaN into the weights here (clip_grad_norm_ + Adam on a NaN gradient); without a clip there is no norm to look at.
+  if (clip_coef && !(fabsf(clip_coef[0]) <= 3.0e38f)) return;
   const float step = lr / bc1, keep = 1.f - lr * decay;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float gi = g[i] * cs;

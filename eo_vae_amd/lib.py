@@ -39,6 +39,9 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_fwd_amax': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     'eovae_conv3x3_f16c8_fwd_mx': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     'eovae_conv3x3_f16c8_which': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    'eovae_conv3x3_f16c8_up_mx_eligible': (_i, [_i, _i, _i, _i, _i]),
+    'eovae_records_mx_from_f32': (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    'eovae_conv3x3_f16c8_up_mx': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
     'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'eovae_conv3x3_f16c8_wgrad_dw_workspace': (_sz, [_i, _i]),
     'eovae_conv3x3_f16c8_wgrad_dw': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
@@ -114,7 +117,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 11  # include/eovae_hip.h; bumped whenever a declared signature changes
+ABI_VERSION = 12  # include/eovae_hip.h; bumped whenever a declared signature changes
 
 
 class EovaeError(RuntimeError):

@@ -687,15 +687,28 @@ def up_conv_subpix(x, weight, bias, want_bwd=False):
     else:
         wp = _subpix_packed(weight, False, f8)
     y = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    # round 6: MX operand records of the low-res x (one HBM pass) + the DMA-fed 16 x 16 kernel that owns both column parities
+    # (csrc/conv_f16c8_q16up.hip); kind 3 in the bench's timer
+    up_mx = bool(f8 and L.load().eovae_conv3x3_f16c8_up_mx_eligible(n, cin, h, w, cout) == 1)
     timed = CONV3X3_TIMER is not None
     if timed:
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
-                                         4.0 * (x.numel() + y.numel() + weight.numel()))
+                                         4.0 * (x.numel() + y.numel() + weight.numel()), 3 if up_mx else 0)
         ev0.record()
     global _LAST_GN_SUMS
     sums = _gn_sums_buffer(n, cout, x.device) if f8 else None
-    _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8,
-               range_amax(x) if f8 else None, gn_sums=sums)
+    if up_mx:
+        lib = L.load()
+        amax = range_amax(x)
+        rec = torch.empty_like(x)
+        L.check(lib.eovae_records_mx_from_f32(L.ptr(x), L.ptr(amax), L.ptr(rec), n, cin, h * w, L.stream()),
+                'eovae_records_mx_from_f32')
+        L.check(lib.eovae_conv3x3_f16c8_up_mx(L.ptr(rec), L.ptr(wp), L.ptr(bias), L.ptr(y), L.ptr(amax), n, cin, h, w, cout,
+                                              L.ptr(sums), GN_GROUPS_HINT if sums is not None else 0, L.stream()),
+                'eovae_conv3x3_f16c8_up_mx')
+    else:
+        _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8,
+                   range_amax(x) if f8 else None, gn_sums=sums)
     _LAST_GN_SUMS = sums
     if timed:
         ev1.record()
@@ -808,6 +821,12 @@ class Conv2dFn(torch.autograd.Function):
         if packed and not (ks == 3 and m == MODE_NORMAL and CONV_PRECISION == 'f16c8'):
             raise L.EovaeError('conv2d: operand-record input (GroupNorm packed output) is only understood by the '
                                "plain 3x3 f16c8 convolution")
+        if packed == 2 and L.load().eovae_records_mx_ok(x.shape[0], cin, x.shape[2], x.shape[3], cout) != 1:
+            # MX operand records are written for ONE consumer (the `cout` hint of group_norm_silu): a layer they were not
+            # meant for would pass the forward and fail in its weight gradient, or -- on the thin kernels -- be read as format 1
+            raise L.EovaeError(f'conv2d: MX operand records (format 2) handed to a layer that does not take them '
+                               f'(Cin {cin}, Cout {cout}, {x.shape[2]}x{x.shape[3]}): the GroupNorm in front was told another '
+                               'consumer (group_norm_silu(..., cout=...)) or a library option changed since')
         ctx.packed = packed
         ctx.wp_bwd = None
         if ks == 3 and m == MODE_UP and res is None and _subpix_ok(weight):

@@ -13,7 +13,9 @@
  *     (PyTorch-ROCm); the library never allocates, frees or retains a pointer past the call
  *   - `stream` is a hipStream_t (0 = default); every call only ENQUEUES work on it, never
  *     synchronises, and is safe to capture into a hipGraph
- *   - re-entrant; no global mutable state except the thread-local error string
+ *   - re-entrant.  Process-wide state the library keeps: the option words below (eovae_set_option), the device
+ *     properties queried once (CU count), the one-pass GroupNorm backward's device-side control block (tickets,
+ *     epoch, time-out record -- eovae_gn_bwd_*), and the thread-local error string.  No tensor is retained.
  *   - scratch needed by a call is passed in (`ws`); sizes come from *_workspace_bytes()
  */
 #ifndef EOVAE_HIP_H
@@ -28,9 +30,24 @@ extern "C" {
 const char* eovae_last_error(void);
 int eovae_abi_version(void);
 const char* eovae_target_arch(void); /* "gfx950" */
-/* Run-time switches for A/B runs and tests (kernel selection only -- never arithmetic).  Each option starts from its
- * environment variable, read once; afterwards only eovae_set_option changes it.  Returns 0 / the value, or a negative
- * status for an unknown name.  Options (environment variable, default):
+/* Run-time switches for A/B runs and tests.  Each option starts from its environment variable, read once; afterwards
+ * only eovae_set_option changes it.  Returns 0 / the value, or a negative status for an unknown name.
+ * Options marked [arithmetic] change the PRODUCTS a kernel forms (every setting is tested against the float64 sum of
+ * exactly its own products, and the defaults are the ones the full-size parity pins are quoted for); the others select
+ * among kernels that form the same products.  Options (environment variable, default):
+ *   "c8_mx"         (EOVAE_C8_MX, 1)          [arithmetic] correction product on block-scaled MX-FP6 (e2m3) operands where the
+ *                                             kernel and its input allow it (1.64 MFMA units per product); 0: fp8 (e5m2 / e4m3, 2 units)
+ *   "c8_dgrad_mx"   (EOVAE_C8_DGRAD_MX, 1)    [arithmetic] data gradients (fp32 input of the one-wave kernel) quantised to f16 + MX-FP6
+ *                                             inside the kernel; 0: f16 + fp8
+ *   "c8_wgrad_corr" (EOVAE_C8_WGRAD_CORR, 0)  [arithmetic] row-streaming weight gradients: 0 = ONE product f16(dY) * f16(X) (a leaf of the
+ *                                             step: ~3e-4 of a tensor's largest entry, full-size pins unchanged); 1 = f16 product + fp8
+ *                                             correction product (the round-4 arithmetic, ~1e-5) -- the precision / time trade-off to flip
+ *                                             for optimisers that are sensitive to gradient noise
+ *   "c8_q16"        (EOVAE_C8_Q16, 1)         16 x 16 MFMA forms (conv_f16c8_q16.hip, the rows weight gradient): same products, bit-identical
+ *                                             weight gradients, higher held clock; 0: the 32 x 32 forms; 2: also fp32 inputs (measured slower)
+ *   "c8_up_q16"     (EOVAE_C8_UP_Q16, 1)      [arithmetic] x2-upsample forward on MX records of its input (csrc/conv_f16c8_q16up.hip: f16 +
+ *                                             MX-FP6 products); 0: the 8-wave kernel's sub-pixel mode on the fp32 input (f16 + fp8 products)
+ *   "c8_pack_gather" (EOVAE_C8_PACK_GATHER, 0) per-layer weight packs by the per-element gather kernel (bit-identical reference of the LDS-staged pack)
  *   "c8_wgrad_rows" (EOVAE_C8_WGRAD_ROWS, 1)  plain 3x3 weight gradients with record input run the row-streaming kernel
  *   "c8_w4"         (EOVAE_C8_W4, -1)         one-wave-per-SIMD conv kernel: -1 where it pays, 0 never, 1 wherever the shape allows
  *   "c8_w4_ni" (4), "c8_w4_stagger" (0), "c8_w4_skew" (-1)   experiment hooks of that kernel (csrc/conv_f16c8_w4.hip)
@@ -126,6 +143,20 @@ int eovae_conv3x3_f16c8_fwd_mx(const float* x, const void* x6, const void* wp, c
  * conv3x3_f16c8_kernel (8 waves, 8-row tiles: sub-pixel / space-to-depth forms, small grids).  No launch. */
 int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int mode, int subpix,
                               int xpacked);
+/* "nearest x2 + 3x3" forward (layers.py:47-50, Upsample) on MX operand records of the LOW-res input (csrc/conv_f16c8_q16up.hip,
+ * round 6): sub-pixel form (4/9 of the MFMAs), 16 x 16 MFMAs, every byte fed by LDS-DMA, both column parities of the output
+ * in one wave (16-byte stores).  x is not a GroupNorm output here (the residual stream), so its records are written by
+ *   eovae_records_mx_from_f32: x [N][C][HW] fp32 -> rec (N*C*HW*4 bytes: F plane [n][C/8][HW] x 16 B = 8 x f16 | S plane
+ *   [n][C/32][piece][HW] x 16 B = MX-FP6 of (x - f16 x) | x), pre-scaled by the power of two that puts *xamax (float bits of
+ *   max|x|, device, nullable) at 2^13..2^14; C %% 32 == 0.
+ * eovae_conv3x3_f16c8_up_mx: y [N][Cout][2 Hin][2 Win] = conv + bias; wp = eovae_conv3x3_f16c8_pack(eovae_subpix_expand(w))
+ *   (flip 0, 4 Cout rows); xamax = the pointer the records were written with (the scale is undone with the result); gn_sums
+ *   as eovae_conv3x3_f16c8_fwd.  Needs Cin %% 32, Cout %% 128, Hin %% 8, Win %% 32 (..._eligible; library options c8_up_q16,
+ *   c8_mx).  The products are those of the plain forward on MX records: f16(x) f16(w) + the MX-FP6 correction product. */
+int eovae_conv3x3_f16c8_up_mx_eligible(int N, int Cin, int Hin, int Win, int Cout);
+int eovae_records_mx_from_f32(const float* x, const unsigned* xamax, float* rec, int N, int C, int HW, void* stream);
+int eovae_conv3x3_f16c8_up_mx(const float* xrec, const void* wp, const float* bias, float* y, const unsigned* xamax, int N, int Cin,
+                              int Hin, int Win, int Cout, double* gn_sums, int gn_groups, void* stream);
 /* gn_sums (nullable; meant for the forward calls, any subpix form): [N][gn_groups][2] doubles, zero-filled by the caller; the
  * epilogue adds (sum, sum of squares) of the values it stores (bias and residual included) per image and channel
  * group, i.e. the statistics pass of the GroupNorm(gn_groups) that reads y next (layers.py:91-92, 106-108 follow

@@ -418,6 +418,110 @@ def full_step(R):
          grad_norms=norms, grad_samples=samples, bn_running_mean=bn_mean, bn_running_var=bn_var)
 
 
+TRAJ_PROBES = [   # ~20 tensors across the model: 3x3 / 1x1 weights at every level, norms, biases, both hyper-networks
+    'encoder.conv_in.weight_generator.fc_weight.weight', 'encoder.conv_in.weight_generator.transformer_encoder.layers.0.linear1.weight',
+    'encoder.down.0.block.0.conv1.weight', 'encoder.down.0.block.1.conv2.weight', 'encoder.down.0.downsample.conv.weight',
+    'encoder.down.1.block.0.nin_shortcut.weight', 'encoder.down.1.block.0.norm2.weight', 'encoder.down.2.block.1.conv1.weight',
+    'encoder.down.3.block.1.conv1.weight', 'encoder.mid.attn_1.q.weight', 'encoder.mid.block_2.conv2.bias', 'encoder.conv_out.weight',
+    'decoder.conv_in.weight', 'decoder.mid.attn_1.proj_out.weight', 'decoder.up.3.block.0.conv1.weight', 'decoder.up.3.upsample.conv.weight',
+    'decoder.up.2.block.2.conv2.weight', 'decoder.up.1.block.0.nin_shortcut.weight', 'decoder.up.1.upsample.conv.weight',
+    'decoder.up.0.block.2.conv1.weight', 'decoder.norm_out.weight', 'decoder.conv_out.weight_generator.fc_weight.weight',
+]
+
+
+TRAJ_LR = 1e-5   # see full_traj's docstring
+TRAJ_SAMPLES = 256
+
+
+def full_traj(R):
+    """THREE consecutive optimiser steps of the reference at full size: the step sequence of
+    new_autoencoder.py:587-652 -- forward with the posterior noise injected, Charbonnier + 1e-6 KL, backward,
+    clip_grad_norm_(1.0), Adam.step() (configure_optimizers :549-556) -- at a constant LR of 1e-5: the reference's own
+    training ramps the LR from 0 to base_lr = 1e-4 over 2000 warm-up steps (5e-8 per step: three steps from 0 would move
+    nothing), and a constant 1e-4 on the closed-form fill is outside any regime the reference trains in (generated and looked
+    at: loss 2.2 -> 10.9 -> 3.8, KL x 300, and the fp32 oracle already drifts 35 x per step from the fp32 reference) -- 1e-5 is
+    the schedule's value at step 200, moves every weight by ~3e-4 of its RMS per step, and stays stable.  On the
+    configs/eo-vae.yaml model, B = 2, S2RGB 256x256, a new batch and a new draw per step.  Stored per step: loss, its
+    terms, the pre-clip gradient norm; after step 3: for ~20 named tensors the norm of (p3 - p0) and 256 sampled entries of it,
+    the norm of p0, and a subsample of the THIRD step's reconstruction (it saw two updates).  What it pins that the one-step
+    fixture cannot: what the gradient arithmetic (one-f16-product weight gradients feeding Adam) does to the trajectory."""
+    print('full-size cfg2 three-step trajectory fixture (B=2, S2RGB, 256x256) -- takes ~5 min')
+    from einops import rearrange
+    F = torch.nn.functional
+    cfg = O.model_cfg()
+    ref = R.vae.EOFluxVAE(R.model.Encoder(**cfg['encoder']), R.model.Decoder(**cfg['decoder']),
+                          torch.nn.Identity(), freeze_body=False)
+    O.det_fill(ref, seed=31)
+    ref.train()
+    ns = {'torch': torch, 'nn': torch.nn, 'F': F}
+    Charb = ref_class_from_source(os.path.join(REF, 'eo_vae/models/modules/consistency_loss.py'), 'CharbonnierLoss', ns)()
+    mine = O.build_vae(cfg)
+    O.det_fill(mine, seed=31)
+    mine.train()
+    wvs = torch.tensor(O.WAVELENGTHS['S2RGB'])
+    params_r = [p for p in ref.encoder.parameters() if p.requires_grad] + [p for p in ref.decoder.parameters() if p.requires_grad]
+    params_o = [p for p in mine.encoder.parameters() if p.requires_grad] + [p for p in mine.decoder.parameters() if p.requires_grad]
+    lr = float(os.environ.get('EOVAE_TRAJ_LR', TRAJ_LR))
+    opt_r = torch.optim.Adam(params_r, lr=lr)            # new_autoencoder.py:556
+    opt_o = torch.optim.Adam(params_o, lr=lr)
+    named_r = dict([('encoder.' + k, p) for k, p in ref.encoder.named_parameters()] +
+                   [('decoder.' + k, p) for k, p in ref.decoder.named_parameters()])
+    named_o = dict([('encoder.' + k, p) for k, p in mine.encoder.named_parameters()] +
+                   [('decoder.' + k, p) for k, p in mine.decoder.named_parameters()])
+    assert all(k in named_r for k in TRAJ_PROBES), [k for k in TRAJ_PROBES if k not in named_r]
+    p0 = {k: named_r[k].detach().clone() for k in TRAJ_PROBES}
+    out = {}
+    for step in range(3):
+        x = O.synthetic_batch(2, 3, 256, seed=1300 + step)
+        eps = hashed((2, 32, 32, 32), 1700 + step, 1.0)
+        post = ref.encode(x, wvs)
+        z = post.mean + post.std * eps                       # distributions.py:44-46 with the draw injected
+        zs = rearrange(z, '... c (i pi) (j pj) -> ... (c pi pj) i j', pi=2, pj=2)
+        recon = ref.decode(ref._normalize_latent(zs), wvs)   # new_autoencoder.py:466-478
+        opt_r.zero_grad()
+        char = Charb(recon, x)
+        kl = post.kl().mean()
+        loss = char + 1e-6 * kl
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params_r, 1.0)   # :648-651
+        opt_r.step()
+        # the oracle on the same step
+        rec_o, post_o = mine(x, wvs, noise=eps)
+        opt_o.zero_grad()
+        loss_o = O.charbonnier(rec_o, x) + 1e-6 * post_o.kl().mean()
+        loss_o.backward()
+        gn_o = torch.nn.utils.clip_grad_norm_(params_o, 1.0)
+        opt_o.step()
+        e_l = close(loss_o, loss, 2e-5, f'full_traj.loss[{step}]')
+        e_g = close(gn_o, gn, 1e-3, f'full_traj.gnorm[{step}]')
+        e_r = close(rec_o, recon, 2e-4, f'full_traj.recon[{step}]')
+        print(f'  step {step}: loss {loss.item():.6f} gnorm {gn.item():.4f}; oracle vs reference: loss {e_l:.1e} gnorm {e_g:.1e} recon {e_r:.1e}')
+        out[f'x_checksum{step}'] = np.float64(x.double().sum().item())
+        out[f'eps{step}'] = npy(eps)
+        out[f'loss{step}'] = np.float64(loss.item())
+        out[f'charbonnier{step}'] = np.float64(char.item())
+        out[f'kl{step}'] = np.float64(kl.item())
+        out[f'gnorm{step}'] = np.float64(gn.item())
+        if step == 2:
+            out['recon2_sub'] = npy(recon[:, :, ::8, ::8])
+    worst = 0.0
+    dn, d0, ds = [], [], []
+    for k in TRAJ_PROBES:
+        d_r = (named_r[k].detach() - p0[k]).double()
+        d_o = (named_o[k].detach() - p0[k]).double()
+        worst = max(worst, (d_o - d_r).norm().item() / d_r.norm().item())
+        dn.append(d_r.norm().item())
+        d0.append(p0[k].double().norm().item())
+        ds.append(npy(d_r.float()).reshape(-1)[sample_index(d_r.numel(), TRAJ_SAMPLES)])
+    print(f'  oracle vs reference: worst parameter-delta error after 3 steps {worst:.2e} (relative to the delta\'s norm)')
+    assert worst < 0.05, worst
+    out.update(lr=np.float64(lr), probe_names=np.array(TRAJ_PROBES), delta_norms=np.array(dn), p0_norms=np.array(d0), delta_samples=np.stack(ds),
+               oracle_worst_delta_err=np.float64(worst),
+               bn_running_mean=npy(ref.bn.running_mean), bn_running_var=npy(ref.bn.running_var))
+    save('full_cfg2_traj', **out)
+
+
+
 def full_step12(R):
     """cfg3's arithmetic path at FULL size on the reference itself: the same train step as
     full_step, on S2L2A (12 wavelengths, terramesh_datamodule.py:21-34), B=2, 256x256.  At C = 12 the first / last
@@ -759,7 +863,8 @@ if __name__ == '__main__':
               ('distill', lambda: distill(R)),
               ('running_stats', running_stats), ('batch_prep', batch_prep),
               ('full_size', lambda: full_size(R)), ('full_step', lambda: full_step(R)),
-              ('full_step12', lambda: full_step12(R)), ('full_encode', lambda: full_encode(R))]
+              ('full_step12', lambda: full_step12(R)), ('full_encode', lambda: full_encode(R)),
+              ('full_traj', lambda: full_traj(R))]
     for name, fn in groups:
         if not only or name in only:
             fn()

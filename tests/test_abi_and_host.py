@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, s), f'{s} declared in include/eovae_hip.h but not exported'
     # the ctypes table mirrors the header one to one
     assert sorted(L.SIGNATURES) == syms
-    assert cdll.eovae_abi_version() == L.ABI_VERSION == 11
+    assert cdll.eovae_abi_version() == L.ABI_VERSION == 12
     cdll.eovae_target_arch.restype = ctypes.c_char_p
     assert cdll.eovae_target_arch() == b'gfx950'
 

@@ -697,3 +697,47 @@ def test_range_guard_bound_from_groupnorm_sums():
         assert eb < 3e-5 and ee < 3e-5, (eb, ee)
     finally:
         ops.CONV_PRECISION, ops.AMAX_FROM_SUMS = old, keep
+
+
+def test_fused_adam_skips_a_step_whose_gradient_norm_is_not_finite():
+    """Fault containment (csrc/optim.hip): a NaN anywhere in the clipped gradient -- what a GroupNorm-backward time-out leaves
+    in dgamma / dbeta, and what the all-reduce then hands to every rank -- makes the fused Adam launch a no-op: parameters
+    and moments stay as they were (and finite), so no checkpoint written before the host raises is corrupt."""
+    from eo_vae_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(257, device='cuda')), torch.nn.Parameter(torch.randn(33, 5, device='cuda'))]
+    opt = FusedAdam(ps, lr=1e-2)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.clip_grad_norm(1.0)
+    opt.step()                                   # a healthy step moves the parameters
+    before = [p.detach().clone() for p in ps]
+    m_before, v_before = opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+    opt.zero_grad()
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ps[1].grad[2, 3] = float('nan')
+    norm = opt.clip_grad_norm(1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(norm).item()
+    for p, b in zip(ps, before):
+        assert torch.equal(p.detach(), b) and torch.isfinite(p).all()
+    assert torch.equal(opt.exp_avg, m_before) and torch.equal(opt.exp_avg_sq, v_before)
+    opt.zero_grad()
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.clip_grad_norm(1.0)
+    opt.step()                                   # and the step after the fault works again
+    assert not torch.equal(ps[0].detach(), before[0])
+
+
+def test_msssim_forward_is_bit_reproducible():
+    """The per-image sums are block partials folded in a fixed order (csrc/msssim.hip ssim_fold_kernel; round 5 used fp64
+    atomics): two evaluations of the same inputs agree bit for bit, at the benchmark's image size too."""
+    from eo_vae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 4, 256, 256, generator=g).cuda() * 6.0 - 1.0
+    y = (x + 0.3 * torch.randn(3, 4, 256, 256, generator=g).cuda()).clamp(-1.0, 5.0)
+    a, b = ops.msssim(x, y), ops.msssim(x, y)
+    assert torch.equal(a, b) and 0.0 < a.item() < 1.0
