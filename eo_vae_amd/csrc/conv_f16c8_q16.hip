@@ -455,15 +455,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
           sv += o[k];
           qv = __builtin_fmaf(o[k], o[k], qv);
         }
-        if (!(EOVAE_Q16_ABL & 2))
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64, 0);
+        if (!(EOVAE_Q16_ABL & 2))   // (guarded store: a VALU write of the data registers right behind a register-soffset store is a
+                                    // hazard hipcc does not cover on gfx950 -- conv_f16c8_q16_asm.h, tools/probe_store_war.hip)
+          store128_guarded(o, ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
         else
           asm volatile("" :: "v"(o));
       }
       // statistics of the following GroupNorm: every lane's partial (its four pixels x eight pixel tiles of one channel),
       // folded over lane groups and waves by gn_flush().  Written unconditionally, read only when the caller asked for them.
       // (A butterfly over the lane groups by ds_bpermute -- __shfl_xor -- left wrong values in the OUTPUT of the first co
-      // tile: profiles/r05w notes; plain stores instead.)
+      // tile in round 5: profiles/r05w notes; plain LDS cells instead.  Round 6 found the likely cause: the store-data hazard
+      // described at store128_guarded().)
       cell[16 * i] = sv;
       cell[4 * QBM + 16 * i] = qv;
     });

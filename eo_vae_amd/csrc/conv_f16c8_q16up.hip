@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
         s0[0] = o0[0]; s0[1] = o1[0]; s0[2] = o0[1]; s0[3] = o1[1];
         s1[0] = o0[2]; s1[1] = o1[2]; s1[2] = o0[3]; s1[3] = o1[3];
         const int off = i * tile16 + (k >> 1) * rowb2 + (k & 1) * 128;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s0), ysrd, lot, off, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), ysrd, lot, off + 16, 0);
+        store128_guarded(s0, ysrd, lot, off);         // (guarded: conv_f16c8_q16_asm.h -- the compiler re-uses s0 / s1 at once)
+        store128_guarded(s1, ysrd, lot, off + 16);
       }
       cell[16 * i] = sv;
       cell[4 * UBM + 16 * i] = qv;
