@@ -100,6 +100,25 @@ __device__ __forceinline__ void mx6_quant(const float (&v)[32], float amax, i32x
   p0[0] = (int)q[0]; p0[1] = (int)q[1]; p0[2] = (int)q[2]; p0[3] = (int)q[3];
   p1[0] = (int)q[4]; p1[1] = (int)q[5]; p1[2] = (int)sb; p1[3] = 0;
 }
+// 16-byte buffer store with its own wait states (round 6).  MEASURED on gfx950 (tools/probe_store_war.hip,
+// profiles/r06b_probe_store_war.log): a VALU write of a buffer_store_dwordx4's DATA registers issued directly behind the store
+// reaches memory in lanes 12..15 of every 16-lane row (a v_pk_fma_f32's high dword in ~5 % of the stores, a v_mov_b32 in
+// 0.3 %) -- the store reads its data over several cycles.  hipcc 7.2's hazard recogniser inserts its one wait state only for
+// stores WITHOUT a register soffset, and the compiler-scheduled epilogues here use one: conv_f16c8_q16up.hip's first
+// epilogue stored the next pixel tile's value in exactly those lanes, and conv_f16c8_q16.hip's "(iv)" (wrong OUTPUT of the
+// first co tile with a butterfly behind the stores) has the same signature.  The statement below therefore carries the wait
+// states itself: s_nop 4 in front (the descriptor / soffset SGPRs may have come from v_readlane spill restores, which need 5
+// wait states in front of a VMEM read that hipcc does not count for inline assembly), s_nop 3 behind.  ~10 cycles per store
+// against the ~80 a CU needs to drain its 1 KB.
+#ifndef EOVAE_GUARD_STORES
+#define EOVAE_GUARD_STORES 1   // 0 (A/B builds only, tools/build_variant.sh): the plain builtin store
+#endif
+__device__ __forceinline__ void store128_guarded(const f32x4& d, const __amdgpu_buffer_rsrc_t& srd, int voff, int soff) {
+  if (EOVAE_GUARD_STORES)
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" :: "v"(d), "v"(voff), "s"(srd), "s"(soff) : "memory");
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, d), srd, voff, soff, 0);
+}
 // binary exponent of a positive float given as bits (0 for zero / subnormal input)
 __device__ __forceinline__ int expo_of_bits(unsigned bits) {
   const int e = (int)((bits >> 23) & 0xff);

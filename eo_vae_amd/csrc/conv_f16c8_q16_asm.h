@@ -63,19 +63,6 @@ __device__ __forceinline__ void mfma_c(f32x4& c, const i32x6& a, const i32x6& b,
   asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
                : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
-// 16-byte buffer store with its own wait states (round 6).  MEASURED on gfx950 (tools/probe_store_war.hip,
-// profiles/r06b_probe_store_war.log): a VALU write of a buffer_store_dwordx4's DATA registers issued directly behind the store
-// reaches memory in lanes 12..15 of every 16-lane row (a v_pk_fma_f32's high dword in ~5 % of the stores, a v_mov_b32 in
-// 0.3 %) -- the store reads its data over several cycles.  hipcc 7.2's hazard recogniser inserts its one wait state only for
-// stores WITHOUT a register soffset, and the compiler-scheduled epilogues here use one: conv_f16c8_q16up.hip's first
-// epilogue stored the next pixel tile's value in exactly those lanes, and conv_f16c8_q16.hip's "(iv)" (wrong OUTPUT of the
-// first co tile with a butterfly behind the stores) has the same signature.  The statement below therefore carries the wait
-// states itself: s_nop 4 in front (the descriptor / soffset SGPRs may have come from v_readlane spill restores, which need 5
-// wait states in front of a VMEM read that hipcc does not count for inline assembly), s_nop 3 behind.  ~10 cycles per store
-// against the ~80 a CU needs to drain its 1 KB.
-__device__ __forceinline__ void store128_guarded(const f32x4& d, const __amdgpu_buffer_rsrc_t& srd, int voff, int soff) {
-  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" :: "v"(d), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
 #ifndef EOVAE_Q16_SAFE
 #define EOVAE_Q16_SAFE 0   // bisection: 1 every counted vmcnt wait becomes vmcnt(0), 2 every counted lgkmcnt wait lgkmcnt(0)
 #endif

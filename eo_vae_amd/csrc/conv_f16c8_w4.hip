@@ -548,7 +548,9 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
           sv[qq] += o[k];
           qv[qq] = __builtin_fmaf(o[k], o[k], qv[qq]);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ysrd, lot, (i * 4 + qq) * oct + j * rowb, 0);
+        // (guarded: the compiler's schedule had the next quad's v_cndmask write o's first register directly behind this
+        // register-soffset store -- the gfx950 store-data hazard of conv_f16c8_common.h, tools/store_war_lint.py)
+        store128_guarded(o, ysrd, lot, (i * 4 + qq) * oct + j * rowb);
       }
       if constexpr (j == NI - 1) {
         // statistics of the following GroupNorm (the quad's 4 channels lie in one group); written unconditionally,
