@@ -1175,6 +1175,12 @@ class PosteriorSampleFn(torch.autograd.Function):
         moments = _c(moments)
         b, c2, h, w = moments.shape
         z = torch.empty(b, c2 // 2, h, w, dtype=torch.float32, device=moments.device)
+        if eps is not None:
+            # the kernel reads eps with the latent's extents: a smaller tensor is an out-of-bounds read on the device (a test
+            # of round 6 faulted the GPU that way), and the reference's mean + std * eps would raise a broadcast error
+            if tuple(eps.shape) != (b, c2 // 2, h, w) or eps.dtype != torch.float32 or eps.device != moments.device:
+                raise L.EovaeError(f'posterior sample: noise is {tuple(eps.shape)} {eps.dtype} on {eps.device}, the latent is '
+                                   f'{(b, c2 // 2, h, w)} float32 on {moments.device}')
         eps = _c(eps) if eps is not None else None
         L.check(L.load().eovae_posterior_fwd(L.ptr(moments), L.ptr(eps), L.ptr(z), None, b, c2 // 2,
                                              h * w, L.stream()), 'eovae_posterior_fwd')

@@ -741,3 +741,14 @@ def test_msssim_forward_is_bit_reproducible():
     y = (x + 0.3 * torch.randn(3, 4, 256, 256, generator=g).cuda()).clamp(-1.0, 5.0)
     a, b = ops.msssim(x, y), ops.msssim(x, y)
     assert torch.equal(a, b) and 0.0 < a.item() < 1.0
+
+
+def test_posterior_sample_refuses_noise_of_another_shape():
+    """The kernel reads the injected noise with the latent's extents: a tensor of another shape must raise on the host,
+    not read out of bounds on the device (ops.PosteriorSampleFn; the reference's mean + std * eps raises a broadcast error)."""
+    from eo_vae_amd import lib as L
+    from eo_vae_amd.distributions import DiagonalGaussianDistribution
+    post = DiagonalGaussianDistribution(torch.randn(2, 8, 4, 4, device='cuda'))
+    assert post.sample(torch.randn(2, 4, 4, 4)).shape == (2, 4, 4, 4)
+    with pytest.raises(L.EovaeError):
+        post.sample(torch.randn(2, 4, 2, 2))

@@ -194,6 +194,28 @@ def test_full_cfg2_step_fixture(golden):
         assert abs(got - n) <= 2e-4 * max(n, 1e-3 * tot), (k, got, n)
 
 
+def test_full_cfg2_traj_fixture(golden):
+    """The three-step trajectory fixture (gen_golden.py full_traj: the REFERENCE's step sequence at full size, LR 1e-5).  The
+    generator asserted oracle == reference while writing it (loss 1e-6, update 1.9e-4); replaying three full-size steps
+    takes minutes on 8 threads, so the CPU suite checks what is cheap: the three batches are the ones the oracle's
+    synthetic_batch regenerates, the probe tensors exist in the oracle's model, and the stored trajectory is self-consistent
+    (loss = Charbonnier + 1e-6 KL per step; every update moved, none exploded)."""
+    g = golden('full_cfg2_traj')
+    for step in range(3):
+        x = O.synthetic_batch(2, 3, 256, seed=1300 + step)
+        assert abs(x.double().sum().item() - float(g[f'x_checksum{step}'])) < 1e-6
+        assert abs(float(g[f'charbonnier{step}']) + 1e-6 * float(g[f'kl{step}']) - float(g[f'loss{step}'])) < 1e-6 * float(g[f'loss{step}'])
+        assert g[f'eps{step}'].shape == (2, 32, 32, 32) and 10.0 < float(g[f'gnorm{step}']) < 1e3
+    names = dict(O.build_vae(O.model_cfg()).named_parameters())
+    assert len(g['probe_names']) == 22 and g['delta_samples'].shape == (22, 256)
+    assert all(str(k) in names for k in g['probe_names'])
+    lr = float(g['lr'])
+    assert lr == 1e-5 and float(g['oracle_worst_delta_err']) < 1e-3
+    # Adam moves every entry by at most ~lr per step: 0 < ||p3 - p0|| <= 3 lr sqrt(numel), and far below ||p0||
+    assert (g['delta_norms'] > 0).all() and (g['delta_norms'] < 0.05 * g['p0_norms']).all()
+    assert np.abs(g['delta_samples']).max() <= 3.0 * lr * 1.01
+
+
 def test_full_cfg3_step_fixture(golden):
     """BASELINE config 3's arithmetic path at full size (B=2, S2L2A: 12-channel dynamic convolutions first and last):
     the oracle's forward + backward against the fixture the REFERENCE wrote (gen_golden.py full_step12).  The MS-SSIM
