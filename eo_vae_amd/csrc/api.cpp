@@ -34,7 +34,7 @@ const OptDef kOpts[EOVAE_OPT_COUNT] = {
                                                    // and the plain weight gradient; 2 the fp32-input data gradients too (measured 0.88-0.92 x the
                                                    // 32 x 32 kernel: an experiment that stays tested); 0: the 32 x 32 forms
     {"c8_dgrad_mx", "EOVAE_C8_DGRAD_MX", 1},       // the one-wave kernel quantises fp32 inputs (data gradients) to f16 + MX-FP6 itself; 0: f16 + fp8
-    {"c8_up_q16", "EOVAE_C8_UP_Q16", 1},           // x2-upsample forward: MX records of x + conv_f16c8_q16up.hip (both column parities per wave); 0: 8-wave sub-pixel mode
+    {"c8_up_q16", "EOVAE_C8_UP_Q16", 1},           // x2-upsample forward / data gradient on MX records (conv_f16c8_q16up.hip, conv_f16c8_q16upg.hip); 2: data gradient at any tile count; 0: 8-wave sub-pixel modes
 };
 std::atomic<int> g_opt[EOVAE_OPT_COUNT];
 std::atomic<int> g_opt_init{0};

@@ -23,7 +23,7 @@ enum {
   EOVAE_OPT_C8_WGRAD_CORR,    // row-streaming weight gradients WITH the fp8 correction product (the r4 arithmetic): 1; 0 (default): f16 x f16 alone
   EOVAE_OPT_C8_Q16,           // 16 x 16 MFMA shape in the kernels that have that form (1): the chip holds a higher clock on it; 0: 32 x 32
   EOVAE_OPT_C8_DGRAD_MX,      // fp32-input launches of the one-wave kernel (the data gradients) with the MX-FP6 correction product (1); 0: fp8
-  EOVAE_OPT_C8_UP_Q16,        // x2-upsample forward on MX records of its input by conv_f16c8_q16up.hip (1); 0: the 8-wave kernel's sub-pixel mode on fp32 (fp8 correction)
+  EOVAE_OPT_C8_UP_Q16,        // x2-upsample forward / data gradient on MX records (conv_f16c8_q16up.hip, conv_f16c8_q16upg.hip): 1 where it pays, 2 wherever the shape allows, 0: 8-wave sub-pixel modes
   EOVAE_OPT_COUNT
 };
 int eovae_opt(int id);

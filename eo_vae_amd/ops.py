@@ -722,11 +722,25 @@ def up_conv_subpix_dgrad(dy, weight, h, w, wp=None):
     if wp is None:
         wp = _subpix_packed(weight, True, f8)
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
+    # round 6: MX operand records of the high-res dY (one HBM pass) + the DMA-fed 16 x 16 kernel whose K runs over dY's four
+    # parity planes (csrc/conv_f16c8_q16upg.hip); kind 3 in the bench's timer
+    lib = L.load()
+    up_mx = bool(f8 and lib.eovae_conv3x3_f16c8_up_dgrad_mx_eligible(n, cin, h, w, cout) == 1)
     timed = CONV3X3_TIMER is not None
     if timed:
         ev0, ev1 = CONV3X3_TIMER.bracket(2.0 * n * 4 * h * w * cout * cin * 9,
-                                         4.0 * (dy.numel() + dx.numel() + weight.numel()))
+                                         4.0 * (dy.numel() + dx.numel() + weight.numel()), 3 if up_mx else 0)
         ev0.record()
+    if up_mx:
+        amax = amax_of(dy)
+        rec = torch.empty_like(dy)
+        L.check(lib.eovae_records_mx_from_f32(L.ptr(dy), L.ptr(amax), L.ptr(rec), n, cout, 4 * h * w, L.stream()),
+                'eovae_records_mx_from_f32')
+        L.check(lib.eovae_conv3x3_f16c8_up_dgrad_mx(L.ptr(rec), L.ptr(wp), L.ptr(dx), L.ptr(amax), n, cin, h, w, cout, L.stream()),
+                'eovae_conv3x3_f16c8_up_dgrad_mx')
+        if timed:
+            ev1.record()
+        return dx
     oa = zeros_small(1, torch.int32, dy.device) if (f8 and EPILOGUE_AMAX) else None
     _launch3x3(dy, wp, None, None, dx, n, cout, 2 * h, 2 * w, cin, h, w, MODE_NORMAL, 2, f8,
                amax_of(dy) if f8 else None, out_amax=oa)

@@ -45,8 +45,10 @@ const char* eovae_target_arch(void); /* "gfx950" */
  *                                             for optimisers that are sensitive to gradient noise
  *   "c8_q16"        (EOVAE_C8_Q16, 1)         16 x 16 MFMA forms (conv_f16c8_q16.hip, the rows weight gradient): same products, bit-identical
  *                                             weight gradients, higher held clock; 0: the 32 x 32 forms; 2: also fp32 inputs (measured slower)
- *   "c8_up_q16"     (EOVAE_C8_UP_Q16, 1)      [arithmetic] x2-upsample forward on MX records of its input (csrc/conv_f16c8_q16up.hip: f16 +
- *                                             MX-FP6 products); 0: the 8-wave kernel's sub-pixel mode on the fp32 input (f16 + fp8 products)
+ *   "c8_up_q16"     (EOVAE_C8_UP_Q16, 1)      [arithmetic] x2-upsample forward and data gradient on MX records of x / dY (csrc/
+ *                                             conv_f16c8_q16up.hip, conv_f16c8_q16upg.hip: f16 + MX-FP6 products; the data gradient only where it
+ *                                             has a tile per CU); 2: wherever the shape allows; 0: the 8-wave kernel's sub-pixel modes on fp32
+ *                                             inputs (f16 + fp8 products)
  *   "c8_pack_gather" (EOVAE_C8_PACK_GATHER, 0) per-layer weight packs by the per-element gather kernel (bit-identical reference of the LDS-staged pack)
  *   "c8_wgrad_rows" (EOVAE_C8_WGRAD_ROWS, 1)  plain 3x3 weight gradients with record input run the row-streaming kernel
  *   "c8_w4"         (EOVAE_C8_W4, -1)         one-wave-per-SIMD conv kernel: -1 where it pays, 0 never, 1 wherever the shape allows
@@ -157,6 +159,14 @@ int eovae_conv3x3_f16c8_up_mx_eligible(int N, int Cin, int Hin, int Win, int Cou
 int eovae_records_mx_from_f32(const float* x, const unsigned* xamax, float* rec, int N, int C, int HW, void* stream);
 int eovae_conv3x3_f16c8_up_mx(const float* xrec, const void* wp, const float* bias, float* y, const unsigned* xamax, int N, int Cin,
                               int Hin, int Win, int Cout, double* gn_sums, int gn_groups, void* stream);
+/* Data gradient of the same layer (adjoint of layers.py:47-50 w.r.t. its input) on MX operand records of the HIGH-res dY
+ * (csrc/conv_f16c8_q16upg.hip): the GEMM K runs over the four parity planes of dY (a lane's DMA offset is twice the low-res
+ * offset, the parity a constant on the descriptor base), 4 f16 + 2 correction phases per 32 channels of a parity.
+ *   dyrec = eovae_records_mx_from_f32(dY [N][Cout][2 H][2 W], dyamax);  wp = eovae_conv3x3_f16c8_pack(eovae_subpix_expand(w), flip 1);
+ *   dx [N][Cin][H][W].  Needs Cout %% 32, Cin %% 128, H %% 16, W %% 32 (..._eligible; options c8_up_q16, c8_mx). */
+int eovae_conv3x3_f16c8_up_dgrad_mx_eligible(int N, int Cin, int H, int W, int Cout);
+int eovae_conv3x3_f16c8_up_dgrad_mx(const float* dyrec, const void* wp, float* dx, const unsigned* dyamax, int N, int Cin, int H,
+                                    int W, int Cout, void* stream);
 /* gn_sums (nullable; meant for the forward calls, any subpix form): [N][gn_groups][2] doubles, zero-filled by the caller; the
  * epilogue adds (sum, sum of squares) of the values it stores (bias and residual included) per image and channel
  * group, i.e. the statistics pass of the GroupNorm(gn_groups) that reads y next (layers.py:91-92, 106-108 follow

@@ -186,3 +186,62 @@ def test_up_layer_trains_through_the_new_forward():
     yd.backward(gy.double().cpu())
     assert rel(y, yd) < 5e-5 and rel(x.grad, xd.grad) < 1e-4 and rel(b.grad, bd.grad) < 1e-5
     assert rel(wt.grad, wd.grad) < 5e-4       # one-f16-product weight gradient (tests/test_gpu_wgrad_rows.py's bar)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 64, 16, 32), (1, 256, 128, 32, 32), (3, 128, 96, 16, 64)])
+def test_up_data_gradient_equals_the_emulated_product(n, cin, cout, h, w):
+    """dX of the x2-upsample layer on MX records of the high-res dY (csrc/conv_f16c8_q16upg.hip): the float64 sum of the SAME
+    three products -- f16(dY 2^k) x f16(W'), and the two corrections on the block-scaled e2m3 images (blocks of 32 OUTPUT
+    channels per high-res pixel and per weight row / tap) -- over the four parity planes, to summation-order accuracy; the
+    scheme against the fp64 adjoint of the layer as the reference executes it; and the 8-wave kernel's mode it replaces."""
+    from eo_vae_amd import lib as L, ops
+    from oracle import mx_emul as M
+    set_opt(b'c8_up_q16', 2)
+    assert L.load().eovae_conv3x3_f16c8_up_dgrad_mx_eligible(n, cin, h, w, cout) == 1
+    torch.manual_seed(cin + w)
+    wt = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).cuda()
+    dy = (torch.randn(n, cout, 2 * h, 2 * w) * 3e-4).cuda()
+
+    def bwd(q16):     # the op itself (ops.conv2d takes the sub-pixel forms only for Cout % 128 == 0; the kernel needs Cout % 32)
+        set_opt(b'c8_up_q16', 2 * q16)     # 2: the kernel whenever the shape allows (1: only with a tile per CU)
+        dx = ops.up_conv_subpix_dgrad(dy, wt, h, w)
+        torch.cuda.synchronize()
+        return dx
+    dx_new, dx_old = bwd(1), bwd(0)
+    ds = prescale_of(dy.cpu())
+    dyc = dy.cpu() * ds
+    we = folded_weights(wt.cpu())                                 # [4][cout][cin][3][3]
+    want = torch.zeros(n, cin, h, w, dtype=torch.float64)
+    for par in range(4):
+        plane = dyc[:, :, (par >> 1)::2, (par & 1)::2]            # P_p[co][r][c] = dY[co][2 r + py][2 c + px]
+        wf = we[par].flip(2, 3).transpose(0, 1).contiguous()      # data-gradient operand: [cin][cout][kyf][kxf]
+        conv = lambda a_, b_: F.conv2d(a_, b_, padding=1)          # noqa: E731
+        want += M.split_product(plane, wf, conv)                   # K blocks: 32 output channels of the layer on both sides
+    want = want / ds
+    xd = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+    F.conv2d(F.interpolate(xd, scale_factor=2, mode='nearest'), wt.cpu().double(), padding=1).backward(dy.cpu().double())
+    assert rel(dx_new, want) < 3e-6
+    assert rel(dx_new, xd.grad) < 5e-5 and rel(dx_old, xd.grad) < 5e-5
+    assert 1e-8 < rel(dx_new, dx_old) < 5e-5
+
+
+def test_up_data_gradient_at_the_model_shapes_agrees_with_the_8_wave_kernel():
+    """The three layers at the benchmark's batch: every tile of the persistent walk, the XCD map, all four parity planes; against
+    the 8-wave kernel's gather mode, plus linearity in dY (the records' power-of-two pre-scale cancels exactly)."""
+    from eo_vae_amd import ops
+    for n, c, hw in [(16, 512, 32), (16, 512, 64), (16, 256, 128)]:
+        torch.manual_seed(hw + 1)
+        wt = torch.randn(c, c, 3, 3, device='cuda') / (c * 9) ** 0.5
+        dy = torch.randn(n, c, 2 * hw, 2 * hw, device='cuda') * 1e-4
+        out = {}
+        for q, scale in ((1, 1.0), (1, 8.0), (0, 1.0)):
+            set_opt(b'c8_up_q16', 2 * q)
+            x = torch.zeros(n, c, hw, hw, device='cuda', requires_grad=True)
+            ops.conv2d(x, wt, None, None, 'up').backward(dy * scale)
+            out[(q, scale)] = x.grad
+            del x
+        torch.cuda.synchronize()
+        assert rel(out[(1, 1.0)], out[(0, 1.0)]) < 5e-5
+        assert torch.equal(out[(1, 8.0)], out[(1, 1.0)] * 8.0)
+        del out, wt, dy
+        torch.cuda.empty_cache()
