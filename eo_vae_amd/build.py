@@ -47,6 +47,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                         for h in glob.glob(os.path.join(CSRC, '*.h')))):
             continue
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
+        if os.environ.get('EOVAE_BUILD_PARKED') == '1':    # the measured-and-parked kernels too (csrc/eovae_common.h); use --force
+            cmd.insert(1, '-DEOVAE_PARKED=1')
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -78,4 +78,5 @@ int eovae_get_option(const char* name) {
 }
 int eovae_abi_version(void) { return 12; }  // 12: eovae_conv3x3_f16c8_up_mx, eovae_records_mx_from_f32 (x2-upsample forward on MX records); 11: MX-FP6 correction product (eovae_gn_silu_fwd_packed_mx, eovae_conv3x3_f16c8_fwd_mx, 24 KiB weight tiles); 3: f16c8 convolution entries; 4: gn_silu_bwd reports max|dx|; 5: f16c8 operand records (xpacked); 6: GroupNorm sums from the conv epilogue; 7: f16c8 wgrad takes xamax (range guard), conv3x3_f16c8_which, gn_bwd_fused switches; 8: conv3x3_thin_wgrad; 9: eovae_set_option / eovae_get_option; 10: eovae_gen_* (weight generators)
 const char* eovae_target_arch(void) { return "gfx950"; }
+int eovae_build_flags(void) { return EOVAE_PARKED ? 1 : 0; }   // bit 0: the parked kernels are compiled in (eovae_common.h)
 }

@@ -659,7 +659,7 @@ extern "C" int eovae_debug_q16_stamps(void* dst, size_t bytes) {
 // (a.x6 is not looked at: eovae_conv3x3_f16c8_which() asks without pointers; the entry sets it for every packed == 2 call)
 bool eovae_c8_q16_eligible(const ConvCArgs& a) {
   const int opt = eovae_opt(EOVAE_OPT_C8_Q16);   // 0: never, 1: MX record inputs, 2: fp32 inputs (data gradients) too
-  return opt != 0 && (a.packed == 2 || (a.packed == 0 && opt >= 2 && eovae_opt(EOVAE_OPT_C8_MX))) && a.Hout % 16 == 0 &&
+  return opt != 0 && (a.packed == 2 || (EOVAE_PARKED && a.packed == 0 && opt >= 2 && eovae_opt(EOVAE_OPT_C8_MX))) && a.Hout % 16 == 0 &&
          (!a.gn_sums || a.gn_shift <= 6) && (size_t)a.Hin * a.Win * 32 * 4 < (1ull << 31) &&   // (the fp32 path's out-of-range marker 2^31 must lie beyond a chunk's 32 planes)
          // the epilogue's 32-bit byte arithmetic: a co-block's span of y (descriptor range) and 7 * tile16 + lot stay below 2^31
          (size_t)QBM * a.Hout * a.Wout * 4 < (1ull << 31) &&
@@ -669,6 +669,11 @@ bool eovae_c8_q16_eligible(const ConvCArgs& a) {
 // a: prepared by eovae_c8_w4_launch (tiles, ntiles, xcd_remap)
 void eovae_c8_q16_launch(const ConvCArgs& a, int n_cu, hipStream_t st) {
   const dim3 grid((unsigned)(a.ntiles < n_cu ? a.ntiles : n_cu)), blk(256);
-  if (a.packed == 2) hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel<false>, grid, blk, 0, st, a);
-  else hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel<true>, grid, blk, 0, st, a);
+#if EOVAE_PARKED   // the fp32-input path (measured 0.88-0.92 x conv_f16c8_w4.hip's): compiled only into parked builds
+  if (a.packed != 2) {
+    hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel<true>, grid, blk, 0, st, a);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(conv3x3_f16c8_q16_kernel<false>, grid, blk, 0, st, a);
 }

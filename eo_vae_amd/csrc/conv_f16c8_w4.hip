@@ -787,7 +787,7 @@ extern "C" int eovae_debug_w4_stamps(void* dst, size_t bytes) {
 // variant spills 50 registers into the phase sequence and is not used.
 static int w4_rows_per_wave(const ConvCArgs& a, int n_cu) {
   (void)n_cu;
-  if (eovae_opt(EOVAE_OPT_C8_W4_NI) == 2 && a.packed == 1 && a.Hout % 8 == 0) return 2;
+  if (EOVAE_PARKED && eovae_opt(EOVAE_OPT_C8_W4_NI) == 2 && a.packed == 1 && a.Hout % 8 == 0) return 2;   // (parked instantiations)
   return a.Hout % 16 == 0 ? 4 : 0;
 }
 
@@ -829,10 +829,13 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
     eovae_c8_q16_launch(a, n_cu, st);
     return;
   }
+#if EOVAE_PARKED
   if (ni == 2) {
     if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 2, false>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 2, false>), grid, blk, 0, st, a);
-  } else {
+  } else
+#endif
+  {
     if (a.mx) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, true>), grid, blk, 0, st, a);
     else if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, false>), grid, blk, 0, st, a);
     // fp32 input (the data gradients): MX-FP6 correction product quantised in the kernel (library options c8_mx, c8_dgrad_mx)

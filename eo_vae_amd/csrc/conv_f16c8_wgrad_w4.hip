@@ -30,6 +30,7 @@
 
 #include "conv_f16c8_common.h"
 
+#if EOVAE_PARKED
 namespace {
 
 #ifndef EOVAE_WG4_ABL
@@ -431,6 +432,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_f16c8_w4_kernel(WgCArgs a) {
 // every one of them must fit an MFMA gap of the SAME wave, and 1 300 x ~4.5 issue cycles do not (dY conversion 240,
 // LDS-DMA issue and addressing 200, fragment reads 176, SGPR-spill lane moves 130, waits 86, dY loads + 64-bit
 // addressing 90, tile decode 80 ...), while the 8-wave kernel spreads the same staging over two waves per SIMD.
+#else   // not compiled in: the option reads as "not available"
+bool eovae_c8_wgrad_w4_eligible(const WgCArgs&) { return false; }
+void eovae_c8_wgrad_w4_launch(WgCArgs, hipStream_t) {}
+#endif
+#if EOVAE_PARKED
 bool eovae_c8_wgrad_w4_eligible(const WgCArgs& a) {
   if (eovae_opt(EOVAE_OPT_C8_WGRAD_W4) != 1) return false;
   if (a.subpix != 0 || a.mode != MODE_NORMAL || !a.xpacked) return false;
@@ -442,3 +448,4 @@ void eovae_c8_wgrad_w4_launch(WgCArgs a, hipStream_t st) {
   const dim3 grid(a.ncib * a.ncob_ * a.split), blk(256);
   hipLaunchKernelGGL(wgrad3x3_f16c8_w4_kernel, grid, blk, 0, st, a);
 }
+#endif

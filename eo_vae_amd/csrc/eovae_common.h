@@ -28,6 +28,15 @@ enum {
 };
 int eovae_opt(int id);
 
+// Build switch (round 6): measured-and-parked kernels -- the one-wave weight gradient
+// (conv_f16c8_wgrad_w4.hip, 0.77-0.87 x), the 16 x 16 kernel's fp32-input path (conv_f16c8_q16.hip FP32IN, 0.88-0.92 x) and the
+// two-rows-per-wave instantiations of conv_f16c8_w4.hip (round 3's two-blocks-per-CU experiment) -- are compiled only with
+// -DEOVAE_PARKED=1 (EOVAE_BUILD_PARKED=1 python -m eo_vae_amd.build --force).  Their options then read as "not available":
+// the launchers fall back to the default kernels, eovae_build_flags() bit 0 tells tests whether to run their cases.
+#ifndef EOVAE_PARKED
+#define EOVAE_PARKED 0
+#endif
+
 // thread-local last-error text, exported through eovae_last_error()
 void eovae_set_error(const char* fmt, ...);
 

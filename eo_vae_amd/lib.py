@@ -21,6 +21,7 @@ SIGNATURES = {
     'eovae_last_error': (C.c_char_p, []),
     'eovae_abi_version': (_i, []),
     'eovae_target_arch': (C.c_char_p, []),
+    'eovae_build_flags': (_i, []),
     'eovae_clock_probe': (_i, [_p, _p, _i, _i, _p]),
     'eovae_set_option': (_i, [C.c_char_p, _i]),
     'eovae_get_option': (_i, [C.c_char_p]),

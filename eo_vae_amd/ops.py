@@ -1058,7 +1058,9 @@ def gn_timeout_report():
 # Data-parallel runs: a time-out is seen by ONE rank; raising there alone leaves the others in the next bucket all-reduce
 # until RCCL's watchdog fires.  parallel.BucketedGradReducer reduces a fault flag with every step's gradients
 # and installs this hook: it returns True on EVERY rank in the same step once any rank has reported a time-out.
-GN_TIMEOUT_AGREED = None
+GN_TIMEOUT_AGREED = None    # the latest reducer's fault_agreed (kept for callers that look at it; the check walks GN_TIMEOUT_HOOKS)
+GN_TIMEOUT_HOOKS: list = []  # weakref.WeakMethod of every live BucketedGradReducer.fault_agreed (one global slot was
+                             # overwritten by a second reducer and kept a dropped reducer's bound method alive)
 
 
 def raise_on_gn_backward_timeouts():
@@ -1067,12 +1069,16 @@ def raise_on_gn_backward_timeouts():
     optimiser write NaN into every weight.  Sees every launch the host has synchronised with -- at the
     latest one step after the event (data parallel: three steps, and on every rank in the same step)."""
     lib = L.load()
-    if GN_TIMEOUT_AGREED is not None:        # data parallel: the local word stays set until the ranks agree
-        if not GN_TIMEOUT_AGREED():
+    hooks = [h for h in (r() for r in GN_TIMEOUT_HOOKS) if h is not None]   # live reducers only (weak references)
+    if hooks:                                # data parallel: the local word stays set until the ranks agree
+        if not any(h() for h in hooks):
             return
         tok = lib.eovae_gn_bwd_timeouts(0)
         what = gn_timeout_report() if tok else 'reported by another rank'
         lib.eovae_gn_bwd_timeouts(1)
+        if os.environ.get('EOVAE_GN_TIMEOUT_ACTION') == 'warn':      # diagnosis only: every rank sees the same reduced flag, so
+            print(f'[eo_vae_amd] GroupNorm backward time-out agreed by the ranks ({what})', flush=True)   # every rank prints and goes on
+            return
         raise L.EovaeError('GroupNorm backward: a workgroup team timed out waiting for its partial sums on some rank '
                            f'({what}); the gradients of that step are NaN -- set EOVAE_GN_BWD_FUSED=0 to use the two-pass kernels')
     tok = lib.eovae_gn_bwd_timeouts(0)

@@ -83,8 +83,11 @@ class BucketedGradReducer:
             for _ in range(self.HEALTH_LAG + 1):
                 host = torch.zeros(1, dtype=torch.float32)
                 self.health_slots.append([host.pin_memory() if flat.grad.is_cuda else host, None, -1])
+            import weakref
             from . import ops
             ops.GN_TIMEOUT_AGREED = self.fault_agreed
+            self._hook = weakref.WeakMethod(self.fault_agreed)
+            ops.GN_TIMEOUT_HOOKS[:] = [r for r in ops.GN_TIMEOUT_HOOKS if r() is not None] + [self._hook]
             for p in flat.params:
                 if p.requires_grad:
                     self.handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -172,3 +175,5 @@ class BucketedGradReducer:
         from . import ops
         if ops.GN_TIMEOUT_AGREED == self.fault_agreed:
             ops.GN_TIMEOUT_AGREED = None
+        hook = getattr(self, '_hook', None)
+        ops.GN_TIMEOUT_HOOKS[:] = [r for r in ops.GN_TIMEOUT_HOOKS if r is not hook and r() is not None]

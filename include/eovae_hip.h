@@ -30,6 +30,9 @@ extern "C" {
 const char* eovae_last_error(void);
 int eovae_abi_version(void);
 const char* eovae_target_arch(void); /* "gfx950" */
+/* bit 0: built with -DEOVAE_PARKED=1, i.e. the measured-and-parked kernels are compiled in (options c8_wgrad_w4 = 1,
+ * c8_q16 = 2 on fp32 inputs, c8_w4_ni = 2 reach them; without the bit those values run the default kernels) */
+int eovae_build_flags(void);
 /* Run-time switches for A/B runs and tests.  Each option starts from its environment variable, read once; afterwards
  * only eovae_set_option changes it.  Returns 0 / the value, or a negative status for an unknown name.
  * Options marked [arithmetic] change the PRODUCTS a kernel forms (every setting is tested against the float64 sum of
