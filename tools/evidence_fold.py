@@ -70,6 +70,20 @@ for k, d in sorted(stats.items(), key=lambda kv: -kv[1]['total_ns']):
         e['sq'] = s
     out['kernels'][k] = e
 out['kernel_ms_per_step_total'] = round(tot / STEPS / 1e6, 3)
+if wl == 'cfg2':
+    # bench.py's `roofline.traffic` reads profiles/r*_pmc_hbm_traffic.json (kernels keyed by base name, all instantiations of a
+    # template together, per-launch means weighted by launches) and quotes it only when csrc_digest matches the build
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for k, p_ in pmc.items():
+        f_, w_ = p_.get('FETCH_SIZE', []), p_.get('WRITE_SIZE', [])
+        if f_ and w_:
+            a_ = agg[re.sub(r'<.*$', '', k)]
+            a_[0] += 1024.0 * sum(f_); a_[1] += 1024.0 * sum(w_); a_[2] += len(f_)
+    old_fmt = {'command': out['command'], 'units': out['units'], 'csrc_digest': out['csrc_digest'], 'conv_precision': out['conv_precision'],
+               'kernels': {k: {'launches': n_, 'fetch_bytes_raw_per_launch': f / n_, 'write_bytes_per_launch': w / n_,
+                               'traffic_bytes_per_launch_raw': (f + w) / n_, 'traffic_bytes_per_launch_corrected': (2 * f + w) / n_}
+                           for k, (f, w, n_) in agg.items() if n_}}
+    json.dump(old_fmt, open(os.path.join(root, f'{tag}_pmc_hbm_traffic.json'), 'w'), indent=1)
 path = os.path.join(root, f'{tag}_{wl}_kernels.json')
 json.dump(out, open(path, 'w'), indent=1)
 print(path, len(out['kernels']), 'kernels,', out['kernel_ms_per_step_total'], 'ms of kernel time per step')
