@@ -133,14 +133,16 @@ def family_roofline(timer, peak, elapsed):
 
 
 def up_roofline(timer, peak, elapsed):
-    """The x2-upsample forward launches on conv_f16c8_q16up.hip (kind 3), measured like `roofline`; algorithmic flops = the
-    layer as the reference executes it (9 taps on the 2x grid; the sub-pixel form does 4/9 of that in MFMAs)."""
+    """The x2-upsample forward / data-gradient launches on conv_f16c8_q16up.hip / conv_f16c8_q16upg.hip (kind 3), measured like
+    `roofline`; algorithmic flops = the layer as the reference executes it (9 taps on the 2x grid; the sub-pixel forms do 4/9 of
+    that in MFMAs)."""
     ms, flops, n = timer.totals(3)
     if n == 0 or ms <= 0:
         return None
     ach = flops / (ms * 1e-3)
     return {'bound': 'mfma', 'kernel': 'conv3x3_f16c8_q16up_kernel (x2-upsample forward on MX records of the low-res input, both column '
-                                       'parities per wave) incl. its records_mx_kernel pass',
+                                       'parities per wave) + conv3x3_f16c8_q16upg_kernel (its data gradient on MX records of dY, K over the '
+                                       'four parity planes), each incl. its records_mx_kernel pass',
             'achieved': round(ach / 1e12, 2), 'achieved_actual_mfma_work': round(ach * 4.0 / 9.0 / 1e12, 2), 'peak': peak / 1e12,
             'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'launches': n, 'achieved_per_launch_ms': round(ms / n, 4),
             'kernel_time_share': round(ms / (elapsed * 1e3), 4)}
