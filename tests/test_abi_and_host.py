@@ -402,3 +402,23 @@ def test_wavelength_embedding_is_memoised_per_tensor_object():
     wg = torch.tensor([0.5, 0.6], requires_grad=True)
     e = DC.wavelength_embedding(64, wg)
     assert e.requires_grad and (id(wg), 64) not in DC._SINCOS_CACHE
+
+
+def test_no_register_write_directly_behind_a_16_byte_buffer_store():
+    """gfx950 store-data hazard (round 6; tools/probe_store_war.hip, profiles/r06b_probe_store_war.log): a VALU write of a
+    buffer_store_dwordx4's data registers issued directly behind the store reaches memory in lanes 12..15 of every 16-lane
+    row, and hipcc 7.2 inserts its wait state only for stores without a register soffset.  The one-wave kernels store through
+    store128_guarded(); this test compiles them and scans the compiler's output (tools/store_war_lint.py): no BUFFER store
+    of 16 bytes may be followed at once by a write of its data.  (Scratch spills and loads that return much later are not the
+    hazard's pattern.)"""
+    import importlib.util
+    import shutil
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    spec = importlib.util.spec_from_file_location('store_war_lint', os.path.join(ROOT, 'tools', 'store_war_lint.py'))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    for name in ('conv_f16c8_q16.hip', 'conv_f16c8_q16up.hip', 'conv_f16c8_q16upg.hip', 'conv_f16c8_w4.hip'):
+        hits = [h for h in lint.scan(os.path.join(ROOT, 'eo_vae_amd', 'csrc', name))
+                if h[0] == 1 and h[1].startswith('buffer_store_dwordx4') and h[2].split()[0].startswith('v_')]
+        assert not hits, (name, hits[:3])

@@ -27,12 +27,11 @@ def store_data(op, rest):
     return regs_of(ops[0] if op.startswith('buffer') else ops[1])
 
 
-total = {1: 0, 2: 0}
-for src in srcs:
+def scan(src):
+    """[(distance, store line, next line)] for one source: data-register writes 1 or 2 instructions behind a multi-dword store."""
     asm = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', src, '-o', '-'],
                          capture_output=True, text=True).stdout
     lines = [l for l in asm.split('\n') if l.strip() and not l.strip().startswith((';', '.', '//')) and not l.strip().endswith(':')]
-    func = '?'
     hits = []
     for i, l in enumerate(lines):
         m = STORE.match(l)
@@ -48,12 +47,22 @@ for src in srcs:
                 dst = regs_of(nxt[len(op):].split(',')[0])
                 if dst & data:
                     hits.append((dist, l.strip(), nxt))
-                    total[dist] += 1
                     break
             if op.startswith(('s_nop', 's_waitcnt')) and dist == 1:
                 break    # a wait state follows the store: safe at distance 1; distance 2 is then at least 2 states away
+    return hits
+
+
+if __name__ != '__main__':
+    srcs = []
+total = {1: 0, 2: 0}
+for src in srcs:
+    hits = scan(src)
+    for h in hits:
+        total[h[0]] += 1
     d1 = [h for h in hits if h[0] == 1]
     print(f'{os.path.basename(src):36s} stores with a data-register write directly behind: {len(d1):3d}   one instruction later: {len(hits) - len(d1):3d}')
     for h in d1[:6]:
         print('    ', h[1], ' || ', h[2])
-print('total distance-1 hazards:', total[1], ' distance-2:', total[2])
+if __name__ == '__main__':
+    print('total distance-1 hazards:', total[1], ' distance-2:', total[2])
