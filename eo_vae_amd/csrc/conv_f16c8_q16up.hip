@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
     const int lob = li * 4;
     const int tile16 = (int)(16 * out_plane * 4), rowb2 = 2 * a.Wout * 4;
     float* const cell = gcell + wave * 8 * UBM + g * UBM + li;
+    float amx = 0.f;   // max |y| of the lane's values (a.out_amax: the range pre-scale of the layer that reads y, without a pass over y)
     static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       __builtin_amdgcn_sched_barrier(0);
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
           sv += o0[e] + o1[e];
           qv = __builtin_fmaf(o0[e], o0[e], qv);
           qv = __builtin_fmaf(o1[e], o1[e], qv);
+          amx = __builtin_fmaxf(amx, __builtin_fmaxf(__builtin_fabsf(o0[e]), __builtin_fabsf(o1[e])));
         }
         f32x4 s0, s1;
         s0[0] = o0[0]; s0[1] = o1[0]; s0[2] = o0[1]; s0[3] = o1[1];
@@ -350,6 +352,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
       cell[16 * i] = sv;
       cell[4 * UBM + 16 * i] = qv;
     });
+    if (a.out_amax) {   // uniform
+      amx = wave_max(amx);
+      if (lane == 0) atomicMax(a.out_amax, __builtin_bit_cast(unsigned, amx));   // non-negative floats order like their bits
+    }
   };
 
   // ---------------------------------------------------------------- prologue
@@ -501,9 +507,10 @@ int eovae_records_mx_from_f32(const float* x, const unsigned* xamax, float* rec,
 
 // y [N][Cout][2 Hin][2 Win] = conv3x3(nearest_x2(x)) + bias, layers.py:47-50.  xrec = MX operand records of x
 // (eovae_records_mx_from_f32 with the same xamax); wp = the f16c8 forward pack of eovae_subpix_expand(w) (4 Cout rows);
-// gn_sums (nullable): [N][gn_groups][2] += (sum, sum of squares) of y per (image, group), as eovae_conv3x3_f16c8_fwd.
+// gn_sums (nullable): [N][gn_groups][2] += (sum, sum of squares) of y per (image, group), as eovae_conv3x3_f16c8_fwd;
+// out_amax (nullable, a pre-zeroed device word): float bits of max|y| by atomicMax from the epilogue.
 int eovae_conv3x3_f16c8_up_mx(const float* xrec, const void* wp, const float* bias, float* y, const unsigned* xamax, int N, int Cin,
-                              int Hin, int Win, int Cout, double* gn_sums, int gn_groups, void* stream) {
+                              int Hin, int Win, int Cout, double* gn_sums, int gn_groups, unsigned* out_amax, void* stream) {
   EOVAE_CHECK_ARG(xrec && wp && y, "conv3x3_f16c8_up_mx: null pointer");
   EOVAE_CHECK_ARG(eovae_conv3x3_f16c8_up_mx_eligible(N, Cin, Hin, Win, Cout),
                   "conv3x3_f16c8_up_mx: shape not supported (N %d Cin %d %dx%d Cout %d; needs Cin %% 32, Cout %% 128, H %% 8, W %% 32)",
@@ -513,7 +520,7 @@ int eovae_conv3x3_f16c8_up_mx(const float* xrec, const void* wp, const float* bi
   a.wp = (const unsigned char*)wp; a.bias = bias; a.res = nullptr; a.y = y; a.xamax = xamax;
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.Hout = 2 * Hin; a.Wout = 2 * Win;
   a.nchunk = Cin / 32; a.cpb = Cout / 128; a.ncob = 4 * a.cpb; a.creal = Cout;
-  a.mode = MODE_NORMAL; a.subpix = 1; a.packed = 2; a.mx = 1; a.stagger = 0; a.skew = 0; a.out_amax = nullptr;
+  a.mode = MODE_NORMAL; a.subpix = 1; a.packed = 2; a.mx = 1; a.stagger = 0; a.skew = 0; a.out_amax = out_amax;
   a.gn_sums = gn_sums; a.gn_groups = gn_groups; a.gn_shift = 0;
   if (gn_sums) {
     const int cpg = gn_groups > 0 && Cout % gn_groups == 0 ? Cout / gn_groups : 0;

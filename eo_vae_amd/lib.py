@@ -42,7 +42,7 @@ SIGNATURES = {
     'eovae_conv3x3_f16c8_which': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     'eovae_conv3x3_f16c8_up_mx_eligible': (_i, [_i, _i, _i, _i, _i]),
     'eovae_records_mx_from_f32': (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    'eovae_conv3x3_f16c8_up_mx': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
+    'eovae_conv3x3_f16c8_up_mx': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     'eovae_conv3x3_f16c8_up_dgrad_mx_eligible': (_i, [_i, _i, _i, _i, _i]),
     'eovae_conv3x3_f16c8_up_dgrad_mx': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'eovae_conv3x3_f16c8_wgrad': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -598,6 +598,9 @@ def _subpix_packed_pair(weight):
     return wp0, wp1
 
 
+DOWN_DGRAD_UP_MX = os.environ.get('EOVAE_DOWN_DGRAD_UP_MX', '1') != '0'   # stride-2 data gradient through conv_f16c8_q16up.hip (0: 8-wave)
+
+
 def _down_ok(x, weight):
     cout, cin = weight.shape[0], weight.shape[1]
     return (SUBPIX_UPSAMPLE and CONV_PRECISION != 'f32' and cin % 128 == 0 and x.shape[2] % 2 == 0
@@ -635,6 +638,23 @@ def down_conv_s2d_dgrad(dy, weight, h, w):
     f8 = _use_f16c8(cout)
     wp = _down_packed(weight, True, f8)
     dx = torch.empty(n, cin, h, w, dtype=torch.float32, device=dy.device)
+    # Round 6: the stride-2 layer's data gradient IS an x2-upsample forward on the space-to-depth weights Wd'' -- parity (py, px) of
+    # dx reads dy through the taps {py, py + 1} x {px, px + 1} of Wd'' (csrc/conv_bf16x3.hip down_expand_kernel: its non-zero taps
+    # lie inside that window), which is conv_f16c8_q16up.hip's tap window exactly.  The kernel multiplies the window's zero taps
+    # too (16 tap groups for 9), and still beats the 8-wave kernel's pixel-shuffle mode where it is taken (DOWN_DGRAD_UP_MX).
+    lib = L.load()
+    # (K = the layer's Cout >= 256: at 128 channels the tile is its epilogue -- 0.392 against 0.391 ms, profiles/r06k_down_layer_ab.log)
+    if f8 and DOWN_DGRAD_UP_MX and cout >= 256 and lib.eovae_conv3x3_f16c8_up_mx_eligible(n, cout, h // 2, w // 2, cin) == 1:
+        amax = amax_of(dy)
+        rec = torch.empty_like(dy)
+        L.check(lib.eovae_records_mx_from_f32(L.ptr(dy), L.ptr(amax), L.ptr(rec), n, cout, (h // 2) * (w // 2), L.stream()),
+                'eovae_records_mx_from_f32')
+        oa = zeros_small(1, torch.int32, dy.device) if EPILOGUE_AMAX else None
+        L.check(lib.eovae_conv3x3_f16c8_up_mx(L.ptr(rec), L.ptr(wp), None, L.ptr(dx), L.ptr(amax), n, cout, h // 2, w // 2, cin,
+                                              None, 0, L.ptr(oa), L.stream()), 'eovae_conv3x3_f16c8_up_mx')
+        if oa is not None:
+            _tag_amax(dx, oa)      # read by the data gradient of the block in front of this layer
+        return dx
     oa = zeros_small(1, torch.int32, dy.device) if (f8 and EPILOGUE_AMAX) else None
     _launch3x3(dy, wp, None, None, dx, n, cout, h // 2, w // 2, cin, h, w, MODE_NORMAL, 4, f8,
                amax_of(dy) if f8 else None, out_amax=oa)
@@ -704,7 +724,7 @@ def up_conv_subpix(x, weight, bias, want_bwd=False):
         L.check(lib.eovae_records_mx_from_f32(L.ptr(x), L.ptr(amax), L.ptr(rec), n, cin, h * w, L.stream()),
                 'eovae_records_mx_from_f32')
         L.check(lib.eovae_conv3x3_f16c8_up_mx(L.ptr(rec), L.ptr(wp), L.ptr(bias), L.ptr(y), L.ptr(amax), n, cin, h, w, cout,
-                                              L.ptr(sums), GN_GROUPS_HINT if sums is not None else 0, L.stream()),
+                                              L.ptr(sums), GN_GROUPS_HINT if sums is not None else 0, None, L.stream()),
                 'eovae_conv3x3_f16c8_up_mx')
     else:
         _launch3x3(x, wp, bias, None, y, n, cin, h, w, cout, 2 * h, 2 * w, MODE_NORMAL, 1, f8,

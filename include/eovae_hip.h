@@ -156,12 +156,14 @@ int eovae_conv3x3_f16c8_which(int N, int Cin, int Hin, int Win, int Cout, int Ho
  *   max|x|, device, nullable) at 2^13..2^14; C %% 32 == 0.
  * eovae_conv3x3_f16c8_up_mx: y [N][Cout][2 Hin][2 Win] = conv + bias; wp = eovae_conv3x3_f16c8_pack(eovae_subpix_expand(w))
  *   (flip 0, 4 Cout rows); xamax = the pointer the records were written with (the scale is undone with the result); gn_sums
- *   as eovae_conv3x3_f16c8_fwd.  Needs Cin %% 32, Cout %% 128, Hin %% 8, Win %% 32 (..._eligible; library options c8_up_q16,
+ *   as eovae_conv3x3_f16c8_fwd, out_amax as eovae_conv3x3_f16c8_fwd_amax.  The stride-2 layer's DATA GRADIENT is the same
+ *   operator on its space-to-depth weights (eovae_down_expand(w, dgrad = 1): xrec = records of dY, Cin = the layer's Cout,
+ *   Cout = the layer's Cin).  Needs Cin %% 32, Cout %% 128, Hin %% 8, Win %% 32 (..._eligible; library options c8_up_q16,
  *   c8_mx).  The products are those of the plain forward on MX records: f16(x) f16(w) + the MX-FP6 correction product. */
 int eovae_conv3x3_f16c8_up_mx_eligible(int N, int Cin, int Hin, int Win, int Cout);
 int eovae_records_mx_from_f32(const float* x, const unsigned* xamax, float* rec, int N, int C, int HW, void* stream);
 int eovae_conv3x3_f16c8_up_mx(const float* xrec, const void* wp, const float* bias, float* y, const unsigned* xamax, int N, int Cin,
-                              int Hin, int Win, int Cout, double* gn_sums, int gn_groups, void* stream);
+                              int Hin, int Win, int Cout, double* gn_sums, int gn_groups, unsigned* out_amax, void* stream);
 /* Data gradient of the same layer (adjoint of layers.py:47-50 w.r.t. its input) on MX operand records of the HIGH-res dY
  * (csrc/conv_f16c8_q16upg.hip): the GEMM K runs over the four parity planes of dY (a lane's DMA offset is twice the low-res
  * offset, the parity a constant on the descriptor base), 4 f16 + 2 correction phases per 32 channels of a parity.

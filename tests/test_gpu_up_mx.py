@@ -245,3 +245,31 @@ def test_up_data_gradient_at_the_model_shapes_agrees_with_the_8_wave_kernel():
         assert torch.equal(out[(1, 8.0)], out[(1, 1.0)] * 8.0)
         del out, wt, dy
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 256, 32, 64), (1, 256, 256, 16, 64), (16, 256, 256, 128, 128)])
+def test_stride2_data_gradient_through_the_upsample_kernel(n, cin, cout, h, w):
+    """The stride-2 layer's data gradient (adjoint of layers.py:33-37) is an x2-upsample forward on the space-to-depth weights
+    Wd'' (ops.down_conv_s2d_dgrad, round 6): against the fp64 adjoint of the layer as the reference executes it (pad (0,1,0,1) +
+    3x3 stride 2), against the 8-wave kernel's pixel-shuffle mode it replaces, and the max|dx| tag from the epilogue against a
+    reduction pass, bit for bit."""
+    from eo_vae_amd import ops
+    torch.manual_seed(cin + h)
+    wt = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).cuda()
+    dy = (torch.randn(n, cout, h // 2, w // 2) * 2e-4).cuda()
+    keep = ops.DOWN_DGRAD_UP_MX
+    try:
+        ops.DOWN_DGRAD_UP_MX = True
+        dx_new = ops.down_conv_s2d_dgrad(dy, wt, h, w)
+        tag = dx_new._eovae_amax
+        assert tag[1] == dx_new._version and torch.equal(tag[0], ops.absmax_bits(dx_new))
+        ops.DOWN_DGRAD_UP_MX = False
+        dx_old = ops.down_conv_s2d_dgrad(dy, wt, h, w)
+    finally:
+        ops.DOWN_DGRAD_UP_MX = keep
+    torch.cuda.synchronize()
+    assert 1e-8 < rel(dx_new, dx_old) < 5e-5
+    if n <= 2:
+        xd = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.pad(xd, (0, 1, 0, 1)), wt.cpu().double(), stride=2).backward(dy.cpu().double())
+        assert rel(dx_new, xd.grad) < 5e-5 and rel(dx_old, xd.grad) < 5e-5
