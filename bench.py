@@ -304,11 +304,20 @@ def clock_probe(device, ms=40.0):
 Q_GN_STEP_PER_IMG = 3 * 1.405e9
 
 
+def f16c8_units(timer, mx_on, dgrad_mx):
+    """MFMA units per algorithmic product of the timed 3x3 forward / data-gradient launches, weighted by their flops."""
+    u = {0: 2.0, 1: 1.64 if (mx_on and dgrad_mx) else 2.0, 2: 1.64 if mx_on else 2.0, 3: 1.64}
+    fl = {k: timer.totals(k)[1] for k in u}
+    tot = sum(fl.values())
+    return sum(fl[k] * u[k] for k in u) / tot if tot > 0 else 2.0
+
+
 def ceiling(conv_flops_step, wgrad_flops_step, batch, ips, units=2.0, clock_ghz=1.77, units_wgrad=None):
     """How far the north_star's 40 % of the HBM-roofline rate is, from this line alone.
     matrix-core floor = algorithmic 3x3 flops of the step (forward + data gradient + weight gradient, as timed above)
-    x MFMA units per product (f16c8: 2 in the data gradient and on fp32 inputs, 1.64 in the MX-FP6 forward of the
-    operand-record layers, 1 in the f16 weight gradients) / dense peak at the clock the chip HOLDS under this load;
+    x MFMA units per product (f16c8: 1.64 on the MX-FP6 kernels -- forward on operand records, data gradients, the x2-upsample
+    kernels --, 2 on the 8-wave kernel's fp32-input forms, 1 in the f16 weight gradients; flops-weighted, f16c8_units) / dense peak
+    at the clock the chip HOLDS under this load;
     HBM floor = the passes no matrix kernel can hide at the HBM peak: GroupNorm (forward apply, backward reduce +
     apply: SURVEY's 3 x 1.405 GB/img) and optimiser / clip / weight traffic (4.8 GB/step);
     1x1 / attention GEMMs, losses, the hyper-network and launch gaps are NOT in the floor (they are ~10 ms today)."""
@@ -565,9 +574,12 @@ def main():
             'roofline_up': up_roofline(timer, peak, elapsed) if dom else None,
             'roofline_other_one_wave': one_wave_roofline(timer, 3 - dom, peak, elapsed) if dom else None,
             'roofline_wgrad': wgrad_roofline(wtimer, peak, elapsed, prec),
-            # f16c8: forward = half of the conv flops, ~0.86 of it (the plain layers behind a GroupNorm) on the MX-FP6 form
+            # f16c8: MFMA units per product as a flops-weighted mean over the launches of the timed region, by the kernel that
+            # took them (no hard-coded MX share): the 16 x 16 kernels on MX records and the x2-upsample kernels 1.64,
+            # the one-wave 32 x 32 kernel 1.64 with the MX data gradient (2.0 without), the 8-wave kernel 2.0 (fp8 correction;
+            # slightly pessimistic for its few MX-record launches)
             'ceiling': ceiling(timer.totals()[1] / args.steps, wtimer.totals()[1] / args.steps, args.batch, ips / world,
-                               ((2.0 - (1.0 if dgrad_mx else 0.5) * 0.86 * (2.0 - 1.64) if mx_on else 2.0) if prec == 'f16c8' else
+                               (f16c8_units(timer, mx_on, dgrad_mx) if prec == 'f16c8' else
                                 (3.0 if prec == 'bf16x3' else (16.0 if prec == 'f32' else 1.0))), clock_ghz,
                                (2.0 if wcorr else 1.0) if prec == 'f16c8' else None)
             if args.workload != 'cfg5' else None,
