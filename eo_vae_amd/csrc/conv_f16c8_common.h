@@ -119,6 +119,30 @@ __device__ __forceinline__ void store128_guarded(const f32x4& d, const __amdgpu_
   else
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, d), srd, voff, soff, 0);
 }
+// Buffer loads as asm statements (issue order = program order; the caller counts the waits and passes the result through
+// landed() behind its s_waitcnt, so that no consumer is scheduled in front of the wait).  s_nop 4: as above, the SGPR operands
+// may come from v_readlane.
+__device__ __forceinline__ void load128_asm(f32x4& d, const __amdgpu_buffer_rsrc_t& srd, int voff, int soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(d) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+template <int OFF>   // (an immediate offset: a register one per call is loop-invariant to the compiler, hoisted and spilled)
+__device__ __forceinline__ void load32_asm(float& d, const __amdgpu_buffer_rsrc_t& srd, int voff) {
+  static_assert(OFF >= 0 && OFF < 4096, "12-bit instruction offset");
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=&v"(d) : "v"(voff), "s"(srd), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void landed(f32x4& d) { asm volatile("" : "+v"(d)); }
+__device__ __forceinline__ void landed(float& d) { asm volatile("" : "+v"(d)); }
+#ifndef EOVAE_EPI_QUADS
+#define EOVAE_EPI_QUADS 1   // 0 (A/B builds only): the epilogues store from the MFMA layout (four lines per lane quad)
+#endif
+// The lane number, re-derived where it is called: values computed from it are NOT loop-invariant to the compiler, which
+// otherwise hoists an epilogue's per-lane addresses out of the tile loop, spills them across the main loop (all 512 registers
+// are taken there) and reloads them between the epilogue's stores -- behind an s_waitcnt vmcnt(0) that drains the stores.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 // binary exponent of a positive float given as bits (0 for zero / subnormal input)
 __device__ __forceinline__ int expo_of_bits(unsigned bits) {
   const int e = (int)((bits >> 23) & 0xff);

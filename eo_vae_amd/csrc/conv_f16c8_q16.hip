@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
 
   // ---------------------------------------------------------------- GroupNorm partial sums
   auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {
-    const int v = tid >> 7, c = tid & 127;
+    const int te = wave * 64 + fresh_lane();
+    const int v = te >> 7, c = te & 127;
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {   // fixed order
@@ -414,58 +415,91 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
 
   // ---------------------------------------------------------------- epilogue
   // acc[i][j][q]: channel 16 i + li, pixel (row j >> 1, column 16 (j & 1) + 4 g + q): four consecutive pixels of one channel
-  // per lane, so every load / store moves 16 bytes per lane with no transposition (a wave instruction covers 16 channel
-  // planes x 64 bytes).  The 32 x 32 form has to transpose 4 x 4 blocks inside lane quads for that (conv_f16c8_w4.hip: ~8 VALU
-  // instructions per value -- 16 k cycles per tile at one wave per SIMD, profiles/r05w_q16_epi_abl.log).
-  auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
+  // per lane, so every load / store moves 16 bytes per lane (a wave instruction covers 16 channel planes x 64 bytes).
+  // WHICH lane holds which 16 bytes decides the rate (round 6, tools/probe_store_pattern.hip, profiles/r06o_*): the memory
+  // pipeline takes a wave's store one QUAD of consecutive lanes at a time, and a quad whose four lanes go to four different
+  // lines (the MFMA layout: consecutive lanes = consecutive channels) costs four times the quad that writes one 64-byte
+  // segment -- 16 against 38..40 bytes per clock and CU.  Every accumulator register is therefore passed through one
+  // ds_bpermute_b32 (lane 4 c + p takes the value of lane 16 p + c: channel c = lane >> 2, pixel group p = lane & 3; the
+  // crossbar only, no LDS bytes) in front of the bias / residual / statistics arithmetic, which runs in the new layout.
+  // Every vector-memory instruction of the epilogue is an asm statement with hand-counted waits.  The queue of one co tile i
+  // (16 channels x the wave's 4 rows x 32 pixels = 8 accumulators) is: residual loads of tile i + 1 (8, only when the layer
+  // has a residual), stores of tile i (8) -- so tile i's residual has landed at vmcnt(16) with the previous tile's stores
+  // still in flight.  (With compiler-counted loads the asm stores were invisible to its wait insertion: "vmcnt(8)" drained
+  // the previous tile's stores in front of every co tile, eight write latencies per tile; and a layer WITHOUT a residual
+  // still issued the 64 zero-range loads -- 16 k of the epilogue's 26 k cycles, profiles/r05w_q16_epi_abl.log.)
+  auto epilogue_tile = [&](const Tile& t, auto resc) __attribute__((always_inline)) {
+    constexpr bool RES = decltype(resc)::value;
+    // (nothing is outstanding here -- the last phase's asm wait -- but the compiler's own scoreboard still holds the main
+    // loop's DMA requests as pending LDS writes and would drain vmcnt(0) in front of a later LDS access of its own, the
+    // statistics cells behind the stores: a wait it can see, where it costs nothing)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     const int co_blk = t.cob * QBM;
-    // buffer addressing and no branch: an absent residual / bias is a descriptor of zero bytes (loads return 0)
     const unsigned span = (unsigned)(QBM * out_plane * 4);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
         a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane, 0, span, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, a.res ? span : 0u, 0x00020000);
+        const_cast<float*>(RES ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, RES ? span : 0u, 0x00020000);
+    // (no branch for an absent bias: a descriptor of zero bytes, the loads return 0)
     const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias + co_blk : a.y), 0, a.bias ? (unsigned)(QBM * 4) : 0u, 0x00020000);
-    const int lot = (int)(((size_t)li * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * g) * 4);
-    const int lob = li * 4;
+    const int le = fresh_lane();
+    const int ec = EOVAE_EPI_QUADS ? le >> 2 : le & 15, ep = EOVAE_EPI_QUADS ? le & 3 : le >> 4;   // channel, pixel group
+    const int psrc = ((ep << 4) | ec) << 2;
+    const int lot = (int)(((size_t)ec * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * ep) * 4);
+    const int lob = ec * 4;
     const int tile16 = (int)(16 * out_plane * 4), rowb = a.Wout * 4;
-    float* const cell = gcell + wave * 8 * QBM + g * QBM + li;
-    // one co tile (16 channels x the wave's 4 rows x 32 pixels = 8 accumulators) at a time; the residual of the next co tile
-    // is requested while this one is written
+    float* const cell = gcell + wave * 8 * QBM + ep * QBM + ec;
+    float bv[8];
+    static_for<0, 8>([&](auto ic) __attribute__((always_inline)) { load32_asm<decltype(ic)::value * 64>(bv[decltype(ic)::value], bsrd, lob); });
     f32x4 rv[2][8];
     auto load_res = [&](f32x4 (&r)[8], int i) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64, 0));
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (RES)
+          load128_asm(r[j], rsrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
+        else
+          r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     };
     load_res(rv[0], 0);
     static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      __builtin_amdgcn_sched_barrier(0);
       if constexpr (i + 1 < 8) load_res(rv[(i + 1) & 1], i + 1);
-      const float bias1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bsrd, lob, i * 64, 0));
+      if constexpr (RES) {
+        wait_vm<(i == 0 || i == 7) ? 8 : 16>();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) landed(rv[i & 1][j]);
+      } else if constexpr (i == 0) {
+        wait_vm<0>();
+      }
+      if constexpr (i == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) landed(bv[k]);
+      }
+      const float bias1 = bv[i];
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          o[k] = __builtin_fmaf(acc[i][j][k], xinv, bias1) + rv[i & 1][j][k];
+          // (the element is copied out first: hipcc 7.2's __builtin_bit_cast of a vector ELEMENT expression reads element 0)
+          const float a0 = acc[i][j][k];
+          const float av = EOVAE_EPI_QUADS
+              ? __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, a0))) : a0;
+          o[k] = __builtin_fmaf(av, xinv, bias1) + rv[i & 1][j][k];
           sv += o[k];
           qv = __builtin_fmaf(o[k], o[k], qv);
         }
         if (!(EOVAE_Q16_ABL & 2))   // (guarded store: a VALU write of the data registers right behind a register-soffset store is a
-                                    // hazard hipcc does not cover on gfx950 -- conv_f16c8_q16_asm.h, tools/probe_store_war.hip)
+                                    // hazard hipcc does not cover on gfx950 -- conv_f16c8_common.h, tools/probe_store_war.hip)
           store128_guarded(o, ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
         else
           asm volatile("" :: "v"(o));
       }
       // statistics of the following GroupNorm: every lane's partial (its four pixels x eight pixel tiles of one channel),
-      // folded over lane groups and waves by gn_flush().  Written unconditionally, read only when the caller asked for them.
-      // (A butterfly over the lane groups by ds_bpermute -- __shfl_xor -- left wrong values in the OUTPUT of the first co
-      // tile in round 5: profiles/r05w notes; plain LDS cells instead.  Round 6 found the likely cause: the store-data hazard
-      // described at store128_guarded().)
+      // folded over pixel groups and waves by gn_flush().  Written unconditionally, read only when the caller asked for them.
       cell[16 * i] = sv;
       cell[4 * QBM + 16 * i] = qv;
     });
@@ -628,9 +662,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
     if (EOVAE_Q16_ABL & 4) {
       Tile fake = cur;
       fake.n = (int)(blockIdx.x % a.N); fake.oy0 = 0; fake.ox0 = (int)((blockIdx.x / a.N) % a.tiles_x) * 32; fake.cob = 0;
-      epilogue_tile(fake);
-    } else
-    epilogue_tile(cur);
+      epilogue_tile(fake, std::false_type{});
+    } else if (a.res) {   // uniform
+      epilogue_tile(cur, std::true_type{});
+    } else {
+      epilogue_tile(cur, std::false_type{});
+    }
     Q16_STAMP(2);
 #if EOVAE_Q16_STAMP
     ++rec;

@@ -89,7 +89,7 @@ __device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
 // where its 32 fp8 bytes sat).  The input is then MX operand records (format 2, groupnorm.hip gn_apply_mx_kernel): the f16
 // octets from the F plane (a.x: [n][Cin / 8][pixel][16 B]), the FP6 pieces from the S plane (a.x6: [n][Cin / 32][piece
 // 0..3][pixel][16 B], piece = wave) -- two 16-byte loads and two 16-byte LDS stores per task.
-template <bool PACKED, int NI, bool MX>
+template <bool PACKED, int NI, bool MX, bool RES>   // RES: the layer adds a residual (a.res != null)
 __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(ConvCArgs a) {
   // FQ (round 5, late): fp32 input WITH the MX-FP6 correction product -- the data gradients.  The block-scaled operands need
   // the 32 channels of a pixel's block in ONE thread (block amax, v_cvt_scalef32_2xpk16_fp6_f32 takes 32 values), so the
@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   constexpr int NTASK = (NPX + 63) / 64;                    // halo tasks per thread: wave w stages channel octet w,
                                                             // lane l pixels l, l + 64, ... (612 = 9 x 64 + 36)
   constexpr int OFF_DUMMY = OFF_GN + GNS;                   // 1 KB that swallows the writes of the last task's idle lanes
-  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_DUMMY + 1024];
-  static_assert(OFF_DUMMY + 1024 <= (NI == 2 ? 80 : 160) * 1024, "LDS");
+  constexpr bool LT = NI == 4;                              // epilogue: accumulator blocks transposed through LDS (below)
+  constexpr int OFF_T = OFF_DUMMY + 1024, TBUF = LT ? 4 * 4096 : 0;   // [wave][32 channels][32 pixels] fp32
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_T + TBUF];
+  static_assert(OFF_T + TBUF <= (NI == 2 ? 80 : 160) * 1024, "LDS");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -447,7 +449,8 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   float* const gslot = reinterpret_cast<float*>(smem + OFF_GN);
   auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {
     // 64 outputs (value v, batch b = (co-tile, channel octet), lane half hh) x 4 waves x 8 lane quads
-    const int out = tid >> 2, sub = tid & 3;
+    const int te = wave * 64 + fresh_lane();   // (not loop-invariant: no spill across the main loop, conv_f16c8_common.h)
+    const int out = te >> 2, sub = te & 3;
     const int v = out >> 5, b = (out >> 1) & 15, hh = out & 1;
     const float* cell = gslot + ((sub * 2 + v) * 16 + b) * 16 + hh * 8;
     const float4 c0 = *reinterpret_cast<const float4*>(cell), c1 = *reinterpret_cast<const float4*>(cell + 4);
@@ -485,56 +488,103 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
       v[c + 2] = e1 ? v[c + 2] : rcv;
     }
   };
+  // Round 6 (tools/probe_store_pattern.hip, profiles/r06o_*): the memory pipeline takes a wave's 16-byte accesses one QUAD of
+  // consecutive lanes at a time, and the transposed layout above -- a quad = four CHANNELS -- costs it four lines per quad
+  // (16 bytes per clock and CU against 38..40 for a quad that covers one 64-byte segment).  Each transposed register
+  // therefore goes through one ds_bpermute_b32 (crossbar only): lane 32 h + 8 m + pq takes the value of lane
+  // 32 h + 4 pq + m and owns channel 8 qq + 4 h + m at pixels 4 pq .. 4 pq + 3 -- a quad = 64 consecutive bytes of one
+  // channel row.  Bias, residual and statistics run in that layout.
+  // Every vector-memory instruction of the epilogue is an asm statement with hand-counted waits (the compiler does not
+  // count asm stores, so its waits for builtin residual loads drained the stores in front of them), a layer without a
+  // residual issues no residual loads (they were 64 zero-range loads per wave), and the per-lane addresses derive from
+  // fresh_lane() so that they are not hoisted out of the tile loop and spilled (conv_f16c8_common.h).
+  // (RES is a kernel parameter, not a branch: with control flow around the epilogue the register allocator copied the
+  // accumulators out of the AGPRs early and spilled hundreds of registers.)
   auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
+    constexpr int T = 4 * NI;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (conv_f16c8_q16.hip epilogue_tile)
     const int co_blk = t.cob * BM;
-    const int m = lane & 3, pq = (lane >> 2) & 7;
-    const bool e0 = lane & 1, e1 = lane & 2;
-    // Buffer addressing, and NO branch in the epilogue: descriptors over the block's 128 channel planes of y and of the
-    // residual and over its 128 bias values; an absent residual / bias is a descriptor of ZERO bytes, whose loads
-    // return 0 by the hardware's range check.  (With `if (residual)` branches between the batches the register
-    // allocator copied the accumulators out of the AGPRs early and spilled 140 registers.)
-    // Lane offset after the transpose: channel 4 h + m of the batch's octet, the wave's first row, its pixel
-    // quartet; batch and row are the scalar offset.
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int le = fresh_lane();
+    const bool e0 = le & 1, e1 = le & 2;
+    // channel 4 eh + em of an octet, pixel quartet epq
+    const int eh = le >> 5, em = (LT || EOVAE_EPI_QUADS) ? (le >> 3) & 3 : le & 3, epq = (LT || EOVAE_EPI_QUADS) ? le & 7 : (le >> 2) & 7;
+    const int psrc = (32 * eh + 4 * epq + em) * 4;
+    float* const tbw = reinterpret_cast<float*>(smem + OFF_T) + wave * 1024 + eh * 4 * 32 + (le & 31);
+    const float* const tbr = reinterpret_cast<const float*>(smem + OFF_T) + wave * 1024 + (le >> 3) * 32 + (le & 7) * 4;
     const unsigned span = (unsigned)(BM * out_plane * 4);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
         a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane, 0, span, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.res ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, a.res ? span : 0u,
-        0x00020000);
+        const_cast<float*>(RES ? a.res + ((size_t)t.n * a.Cout + co_blk) * out_plane : a.y), 0, RES ? span : 0u, 0x00020000);
+    // (no branch for an absent bias: a descriptor of zero bytes, whose loads return 0 by the hardware's range check)
     const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias + co_blk : a.y), 0, a.bias ? (unsigned)(BM * 4) : 0u, 0x00020000);
-    const int lot = (int)(((size_t)(4 * h + m) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * pq) * 4);
-    const int lob = (4 * h + m) * 4;
+    const int lot = (int)(((size_t)(4 * eh + em) * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * epq) * 4);
+    const int lob = (4 * eh + em) * 4;
     const int oct = (int)(8 * out_plane * 4), rowb = a.Wout * 4;
+    float bias1[16];
+    static_for<0, 16>([&](auto bc) __attribute__((always_inline)) { load32_asm<decltype(bc)::value * 32>(bias1[decltype(bc)::value], bsrd, lob); });
     // One accumulator block (co-tile i, row j: 16 channels x this lane's pixel) at a time, so that each 16-register
     // accumulator tuple leaves the AGPRs once and is consumed at once; its residual (4 x 16 bytes) is requested two
-    // blocks ahead (three rotating buffers).
+    // blocks ahead (three rotating buffers).  Queue: L0 L1 | L2 S0 | L3 S1 | ... : behind L(t) come S(t-2) L(t+1) S(t-1) L(t+2).
     auto load_res = [&](f32x4 (&rv)[4], int t) __attribute__((always_inline)) {   // t = NI i + j
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq)
-        rv[qq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrd, lot, ((t / NI) * 4 + qq) * oct + (t % NI) * rowb, 0));
+      for (int qq = 0; qq < 4; ++qq) {
+        if constexpr (RES) load128_asm(rv[qq], rsrd, lot, ((t / NI) * 4 + qq) * oct + (t % NI) * rowb);
+        else rv[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     };
     f32x4 rv0[4], rv1[4], rv2[4];
     load_res(rv0, 0);
     load_res(rv1, 1);
-    float sv[4], qv[4], bias1[4];
-    static_for<0, 4 * NI>([&](auto tc) __attribute__((always_inline)) {
+    float sv[4], qv[4];
+    static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value, i = t / NI, j = t % NI;
       f32x4 (&rv)[4] = (t % 3 == 0) ? rv0 : ((t % 3 == 1) ? rv1 : rv2);
       f32x4 (&rnx)[4] = ((t + 2) % 3 == 0) ? rv0 : (((t + 2) % 3 == 1) ? rv1 : rv2);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (t + 2 < 4 * NI) load_res(rnx, t + 2);
+      if constexpr (t + 2 < T) load_res(rnx, t + 2);
+      if constexpr (RES) {
+        constexpr int behind = (t >= 2 ? 4 : 0) + (t + 1 < T ? 4 : 0) + (t >= 1 ? 4 : 0) + (t + 2 < T ? 4 : 0);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(behind) : "memory");
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) landed(rv[qq]);
+      } else if constexpr (t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if constexpr (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) landed(bias1[k]);
+      }
       if constexpr (j == 0) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-          bias1[qq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bsrd, lob, (i * 4 + qq) * 32, 0));
           sv[qq] = 0.f;
           qv[qq] = 0.f;
         }
       }
       const f32x16 blk = acc[i][j];
+      if constexpr (LT) {
+        // The block (32 channels x the 32 pixels of row j; register 4 qq + k = channel 8 qq + 4 h + k at pixel r) goes
+        // through the wave's 4 KB of LDS: 16 dword writes [channel][pixel] (a wave half = 128 consecutive bytes), 4 reads of
+        // 16 bytes [channel 8 s + (lane >> 3)][pixels 4 (lane & 7) ..] -- eight lanes = one 128-byte channel row, which is
+        // also what the memory pipeline wants of a store (one 64-byte segment per lane quad).  The LDS queue of a wave is
+        // in order: no barrier, and the next block's writes cannot pass this block's reads.
+#pragma unroll
+        for (int c = 0; c < 16; ++c) tbw[((c >> 2) * 8 + (c & 3)) * 32] = blk[c];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(tbr + qq * 8 * 32);
+          f32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            o[k] = __builtin_fmaf(w[k], xinv, bias1[i * 4 + qq]) + rv[qq][k];
+            sv[qq] += o[k];
+            qv[qq] = __builtin_fmaf(o[k], o[k], qv[qq]);
+          }
+          store128_guarded(o, ysrd, lot, (i * 4 + qq) * oct + j * rowb);
+        }
+      } else {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         float w[4];
@@ -544,24 +594,27 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          o[k] = __builtin_fmaf(w[k], xinv, bias1[qq]) + rv[qq][k];
+          const float wk = EOVAE_EPI_QUADS
+              ? __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, w[k]))) : w[k];
+          o[k] = __builtin_fmaf(wk, xinv, bias1[i * 4 + qq]) + rv[qq][k];
           sv[qq] += o[k];
           qv[qq] = __builtin_fmaf(o[k], o[k], qv[qq]);
         }
-        // (guarded: the compiler's schedule had the next quad's v_cndmask write o's first register directly behind this
-        // register-soffset store -- the gfx950 store-data hazard of conv_f16c8_common.h, tools/store_war_lint.py)
+        // (guarded: the gfx950 store-data hazard of conv_f16c8_common.h, tools/store_war_lint.py)
         store128_guarded(o, ysrd, lot, (i * 4 + qq) * oct + j * rowb);
       }
+      }
       if constexpr (j == NI - 1) {
-        // statistics of the following GroupNorm (the quad's 4 channels lie in one group); written unconditionally,
-        // read by gn_flush() only when the caller asked for them
+        // statistics of the following GroupNorm; written unconditionally, read by gn_flush() only when the caller asked
+        // for them.  A quad holds four pixel quartets of ONE channel; the 8 cells of a lane half (lane >> 2 = 8 h + ...)
+        // together cover its 4 channels (one group: gn_shift >= 2) x 32 pixels, which is all gn_flush() sums.
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           float s1 = sv[qq], q1 = qv[qq];
           s1 += dpp_quad<0xB1>(s1); q1 += dpp_quad<0xB1>(q1);
           s1 += dpp_quad<0x4E>(s1); q1 += dpp_quad<0x4E>(q1);
-          float* cell = gslot + (wave * 32 + i * 4 + qq) * 16 + (lane >> 2);
-          if ((lane & 3) == 0) {
+          float* cell = gslot + (wave * 32 + i * 4 + qq) * 16 + (le >> 2);
+          if ((le & 3) == 0) {
             cell[0] = s1;
             cell[16 * 16] = q1;
           }
@@ -829,18 +882,26 @@ void eovae_c8_w4_launch(ConvCArgs a, int n_cu, hipStream_t st) {
     eovae_c8_q16_launch(a, n_cu, st);
     return;
   }
+  auto launch = [&](auto pc, auto nc, auto mc) {
+    constexpr bool P = decltype(pc)::value, M = decltype(mc)::value;
+    constexpr int NI_ = decltype(nc)::value;
+    if (a.res) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<P, NI_, M, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<P, NI_, M, false>), grid, blk, 0, st, a);
+  };
+  using std::integral_constant;
+  typedef std::true_type Y;
+  typedef std::false_type N;
 #if EOVAE_PARKED
   if (ni == 2) {
-    if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 2, false>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 2, false>), grid, blk, 0, st, a);
+    if (a.packed) launch(Y{}, integral_constant<int, 2>{}, N{});
+    else launch(N{}, integral_constant<int, 2>{}, N{});
   } else
 #endif
   {
-    if (a.mx) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, true>), grid, blk, 0, st, a);
-    else if (a.packed) hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<true, 4, false>), grid, blk, 0, st, a);
+    if (a.mx) launch(Y{}, integral_constant<int, 4>{}, Y{});
+    else if (a.packed) launch(Y{}, integral_constant<int, 4>{}, N{});
     // fp32 input (the data gradients): MX-FP6 correction product quantised in the kernel (library options c8_mx, c8_dgrad_mx)
-    else if (eovae_opt(EOVAE_OPT_C8_MX) && eovae_opt(EOVAE_OPT_C8_DGRAD_MX))
-      hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4, true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_f16c8_w4_kernel<false, 4, false>), grid, blk, 0, st, a);
+    else if (eovae_opt(EOVAE_OPT_C8_MX) && eovae_opt(EOVAE_OPT_C8_DGRAD_MX)) launch(N{}, integral_constant<int, 4>{}, Y{});
+    else launch(N{}, integral_constant<int, 4>{}, N{});
   }
 }
