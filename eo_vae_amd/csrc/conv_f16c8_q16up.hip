@@ -211,8 +211,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
   const unsigned lds0 = lds0_();
   const unsigned a_f = lds0 + (unsigned)(UOFF_W + g * 2048 + li * 16);
   const unsigned a_c = lds0 + (unsigned)(UOFF_W + (g >> 1) * 8192 + (g & 1) * 4096 + li * 16);
-  const unsigned b_f = lds0 + (unsigned)(UOFF_XF + g * UPPL + (wrow * UXW + li) * 16);
-  const unsigned b_c = lds0 + (unsigned)(UOFF_X6 + 2 * (g & 1) * UPPL + (wrow * UXW + li) * 16) + (unsigned)(g >> 1) * 16u;
+  // MFMA row li of a pixel tile = low-res column bcol (not li): the four rows 4 q .. 4 q + 3 a result lane holds are the column
+  // PAIRS 2 q, 2 q + 1 and 8 + 2 q, 8 + 2 q + 1, so that each of the epilogue's two stores (a pair x both column parities =
+  // 16 bytes per lane) is contiguous over the four lanes of a quad -- see epilogue_tile
+  const int bcol = ((li & 2) << 2) + 2 * (li >> 2) + (li & 1);
+  const unsigned b_f = lds0 + (unsigned)(UOFF_XF + g * UPPL + (wrow * UXW + bcol) * 16);
+  const unsigned b_c = lds0 + (unsigned)(UOFF_X6 + 2 * (g & 1) * UPPL + (wrow * UXW + bcol) * 16) + (unsigned)(g >> 1) * 16u;
 
   f32x4 acc[8][8];   // [co tile of 16][px * 4 + pixel tile (row jr, half hx)]
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -298,7 +302,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
 
   // ---------------------------------------------------------------- GroupNorm partial sums (as conv_f16c8_q16.hip)
   auto gn_flush = [&](int tn, int tcb) __attribute__((always_inline)) {
-    const int v = tid >> 7, c = tid & 127;
+    const int te = wave * 64 + fresh_lane();   // (not loop-invariant: no spill across the main loop, conv_f16c8_common.h)
+    const int v = te >> 7, c = te & 127;
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {   // fixed order
@@ -311,32 +316,49 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
   };
 
   // ---------------------------------------------------------------- epilogue
-  // acc[i][4 px + 2 jr + hx][k]: channel 16 i + li, low-res pixel (row wrow + jr, column 16 hx + 4 g + k), column parity px
-  // -> output row 2 (oy0 + wrow + jr) + py, columns 2 (ox0 + 16 hx + 4 g) + {0..7} = a0 b0 a1 b1 | a2 b2 a3 b3
+  // acc[i][4 px + 2 jr + hx][k]: channel 16 i + li, low-res pixel (row wrow + jr, column 16 hx + {2 g, 2 g + 1, 8 + 2 g,
+  // 9 + 2 g}[k] -- bcol above), column parity px -> output row 2 (oy0 + wrow + jr) + py, columns
+  // 2 (ox0 + 16 hx + 2 g) + {0..3} = a0 b0 a1 b1 and 16 columns further a2 b2 a3 b3.
+  // As conv_f16c8_q16.hip's: every register goes through one ds_bpermute_b32 (lane 4 c + p <- lane 16 p + c: channel c = lane
+  // >> 2, column group p = lane & 3), so that a lane quad writes one 64-byte segment (tools/probe_store_pattern.hip: 2.5 x the
+  // store rate of the MFMA layout's four lines per quad); bias loads are asm with one counted wait, per-lane addresses derive
+  // from fresh_lane() (no hoisting + spill), and the compiler is shown a vmcnt(0) where nothing is outstanding.
   auto epilogue_tile = [&](const Tile& t) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (conv_f16c8_q16.hip epilogue_tile)
     const int co_blk = t.cb * UBM;
     const unsigned span = (unsigned)(UBM * out_plane * 4);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
         a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane, 0, span, 0x00020000);
     const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias + co_blk : a.y), 0, a.bias ? (unsigned)(UBM * 4) : 0u, 0x00020000);
-    const int lot = (int)(((size_t)li * out_plane + (size_t)(2 * (t.oy0 + wrow) + t.py) * a.Wout + 2 * (t.ox0 + 4 * g)) * 4);
-    const int lob = li * 4;
+    const int le = fresh_lane();
+    const int ec = le >> 2, ep = le & 3;   // channel, column group
+    const int psrc = ((ep << 4) | ec) << 2;
+    const int lot = (int)(((size_t)ec * out_plane + (size_t)(2 * (t.oy0 + wrow) + t.py) * a.Wout + 2 * (t.ox0 + 2 * ep)) * 4);
+    const int lob = ec * 4;
     const int tile16 = (int)(16 * out_plane * 4), rowb2 = 2 * a.Wout * 4;
-    float* const cell = gcell + wave * 8 * UBM + g * UBM + li;
+    float* const cell = gcell + wave * 8 * UBM + ep * UBM + ec;
+    float bv[8];
+    static_for<0, 8>([&](auto ic) __attribute__((always_inline)) { load32_asm<decltype(ic)::value * 64>(bv[decltype(ic)::value], bsrd, lob); });
+    wait_vm<0>();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) landed(bv[k]);
     float amx = 0.f;   // max |y| of the lane's values (a.out_amax: the range pre-scale of the layer that reads y, without a pass over y)
+    auto perm = [&](float v) __attribute__((always_inline)) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, v)));
+    };
     static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      __builtin_amdgcn_sched_barrier(0);
-      const float bias1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bsrd, lob, i * 64, 0));
+      const float bias1 = bv[i];
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // pixel tile (jr, hx)
         f32x4 o0, o1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o0[e] = __builtin_fmaf(acc[i][k][e], xinv, bias1);
-          o1[e] = __builtin_fmaf(acc[i][4 + k][e], xinv, bias1);
+          const float a0 = acc[i][k][e], a1 = acc[i][4 + k][e];   // (copied out: __builtin_bit_cast of a vector element, q16.hip)
+          o0[e] = __builtin_fmaf(perm(a0), xinv, bias1);
+          o1[e] = __builtin_fmaf(perm(a1), xinv, bias1);
           sv += o0[e] + o1[e];
           qv = __builtin_fmaf(o0[e], o0[e], qv);
           qv = __builtin_fmaf(o1[e], o1[e], qv);
@@ -346,15 +368,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16up_kernel(ConvCArgs a
         s0[0] = o0[0]; s0[1] = o1[0]; s0[2] = o0[1]; s0[3] = o1[1];
         s1[0] = o0[2]; s1[1] = o1[2]; s1[2] = o0[3]; s1[3] = o1[3];
         const int off = i * tile16 + (k >> 1) * rowb2 + (k & 1) * 128;
-        store128_guarded(s0, ysrd, lot, off);         // (guarded: conv_f16c8_q16_asm.h -- the compiler re-uses s0 / s1 at once)
-        store128_guarded(s1, ysrd, lot, off + 16);
+        store128_guarded(s0, ysrd, lot, off);         // (guarded: conv_f16c8_common.h -- the compiler re-uses s0 / s1 at once)
+        store128_guarded(s1, ysrd, lot, off + 64);
       }
       cell[16 * i] = sv;
       cell[4 * UBM + 16 * i] = qv;
     });
     if (a.out_amax) {   // uniform
       amx = wave_max(amx);
-      if (lane == 0) atomicMax(a.out_amax, __builtin_bit_cast(unsigned, amx));   // non-negative floats order like their bits
+      if (le == 0) atomicMax(a.out_amax, __builtin_bit_cast(unsigned, amx));   // non-negative floats order like their bits
     }
   };
 

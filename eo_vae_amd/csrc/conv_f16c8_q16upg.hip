@@ -236,16 +236,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16upg_kernel(ConvCArgs 
     const unsigned span = (unsigned)(GBM * out_plane * 4);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
         a.y + ((size_t)t.n * a.Cout + co_blk) * out_plane, 0, span, 0x00020000);
-    const int lot = (int)(((size_t)li * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * g) * 4);
+    // (as conv_f16c8_q16.hip's epilogue: lane 4 c + p takes lane 16 p + c's registers, a lane quad then writes one 64-byte
+    // segment; the addresses derive from fresh_lane() so that they are not hoisted out of the tile loop and spilled)
+    const int le = fresh_lane();
+    const int ec = le >> 2, ep = le & 3;   // channel, pixel group
+    const int psrc = ((ep << 4) | ec) << 2;
+    const int lot = (int)(((size_t)ec * out_plane + (size_t)(t.oy0 + wrow) * a.Wout + t.ox0 + 4 * ep) * 4);
     const int tile16 = (int)(16 * out_plane * 4), rowb = a.Wout * 4;
     static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = acc[i][j][k] * xinv;
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = acc[i][j][k];   // (copied out: __builtin_bit_cast of a vector element expression, q16.hip)
+          o[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, a0))) * xinv;
+        }
         store128_guarded(o, ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
       }
     });
