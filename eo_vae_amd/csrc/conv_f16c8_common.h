@@ -130,6 +130,10 @@ __device__ __forceinline__ void load32_asm(float& d, const __amdgpu_buffer_rsrc_
   static_assert(OFF >= 0 && OFF < 4096, "12-bit instruction offset");
   asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=&v"(d) : "v"(voff), "s"(srd), "n"(OFF) : "memory");
 }
+// d = v of lane (byte address / 4): crossbar only, counted by lgkmcnt; an asm statement so that it is ISSUED where it stands
+__device__ __forceinline__ void bpermute_asm(float& d, int lane_bytes, float v) {
+  asm volatile("ds_bpermute_b32 %0, %1, %2" : "=&v"(d) : "v"(lane_bytes), "v"(v));
+}
 __device__ __forceinline__ void landed(f32x4& d) { asm volatile("" : "+v"(d)); }
 __device__ __forceinline__ void landed(float& d) { asm volatile("" : "+v"(d)); }
 #ifndef EOVAE_EPI_QUADS

@@ -423,9 +423,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
   // ds_bpermute_b32 (lane 4 c + p takes the value of lane 16 p + c: channel c = lane >> 2, pixel group p = lane & 3; the
   // crossbar only, no LDS bytes) in front of the bias / residual / statistics arithmetic, which runs in the new layout.
   // Every vector-memory instruction of the epilogue is an asm statement with hand-counted waits.  The queue of one co tile i
-  // (16 channels x the wave's 4 rows x 32 pixels = 8 accumulators) is: residual loads of tile i + 1 (8, only when the layer
-  // has a residual), stores of tile i (8) -- so tile i's residual has landed at vmcnt(16) with the previous tile's stores
-  // still in flight.  (With compiler-counted loads the asm stores were invisible to its wait insertion: "vmcnt(8)" drained
+  // (16 channels x the wave's 4 rows x 32 pixels = 8 accumulators) is: residual loads of tile i + 2 (8, only when the layer
+  // has a residual), stores of tile i (8) -- so tile i's residual has landed at vmcnt(32) with the two previous tiles' stores
+  // and the next tile's loads still in flight.  (With compiler-counted loads the asm stores were invisible to its wait insertion: "vmcnt(8)" drained
   // the previous tile's stores in front of every co tile, eight write latencies per tile; and a layer WITHOUT a residual
   // still issued the 64 zero-range loads -- 16 k of the epilogue's 26 k cycles, profiles/r05w_q16_epi_abl.log.)
   auto epilogue_tile = [&](const Tile& t, auto resc) __attribute__((always_inline)) {
@@ -452,56 +452,89 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16c8_q16_kernel(ConvCArgs a) 
     float* const cell = gcell + wave * 8 * QBM + ep * QBM + ec;
     float bv[8];
     static_for<0, 8>([&](auto ic) __attribute__((always_inline)) { load32_asm<decltype(ic)::value * 64>(bv[decltype(ic)::value], bsrd, lob); });
-    f32x4 rv[2][8];
-    auto load_res = [&](f32x4 (&r)[8], int i) __attribute__((always_inline)) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if constexpr (RES)
-          load128_asm(r[j], rsrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
-        else
-          r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    };
-    load_res(rv[0], 0);
-    static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int i = decltype(ic)::value;
-      if constexpr (i + 1 < 8) load_res(rv[(i + 1) & 1], i + 1);
-      if constexpr (RES) {
-        wait_vm<(i == 0 || i == 7) ? 8 : 16>();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) landed(rv[i & 1][j]);
-      } else if constexpr (i == 0) {
-        wait_vm<0>();
-      }
-      if constexpr (i == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) landed(bv[k]);
-      }
-      const float bias1 = bv[i];
-      float sv = 0.f, qv = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        f32x4 o;
+    auto finish = [&](f32x4& o, float& sv, float& qv, int i, int j) __attribute__((always_inline)) {
+      if (!(EOVAE_Q16_ABL & 16)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          // (the element is copied out first: hipcc 7.2's __builtin_bit_cast of a vector ELEMENT expression reads element 0)
-          const float a0 = acc[i][j][k];
-          const float av = EOVAE_EPI_QUADS
-              ? __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, a0))) : a0;
-          o[k] = __builtin_fmaf(av, xinv, bias1) + rv[i & 1][j][k];
           sv += o[k];
           qv = __builtin_fmaf(o[k], o[k], qv);
         }
-        if (!(EOVAE_Q16_ABL & 2))   // (guarded store: a VALU write of the data registers right behind a register-soffset store is a
-                                    // hazard hipcc does not cover on gfx950 -- conv_f16c8_common.h, tools/probe_store_war.hip)
-          store128_guarded(o, ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
-        else
-          asm volatile("" :: "v"(o));
       }
-      // statistics of the following GroupNorm: every lane's partial (its four pixels x eight pixel tiles of one channel),
-      // folded over pixel groups and waves by gn_flush().  Written unconditionally, read only when the caller asked for them.
-      cell[16 * i] = sv;
-      cell[4 * QBM + 16 * i] = qv;
+      if (!(EOVAE_Q16_ABL & 2))   // (guarded store: a VALU write of the data registers right behind a register-soffset store is a
+                                  // hazard hipcc does not cover on gfx950 -- conv_f16c8_common.h, tools/probe_store_war.hip)
+        store128_guarded(o, ysrd, lot, i * tile16 + (j >> 1) * rowb + (j & 1) * 64);
+      else
+        asm volatile("" :: "v"(o));
+    };
+    // statistics of the following GroupNorm: every lane's partial (its four pixels x eight pixel tiles of one channel), folded
+    // over pixel groups and waves by gn_flush().  Written unconditionally, read only when the caller asked for them.
+    // Unit u = half a co tile (co tile u >> 1, pixel tiles 4 (u & 1) .. + 3: 16 registers).  Two things run AHEAD of the
+    // arithmetic, as asm statements with counted waits:
+    //   the lane permutation, one unit (issued where the compiler places the builtin -- in front of the values' use -- every
+    //   batch of eight exposed the LDS latency);
+    //   the residual loads, RA units (one co tile ahead left ~17 k cycles of exposed load latency per tile,
+    //   profiles/r06o_q16_stamps_pipelined.log).  Queue: L0 .. L(RA-1) | L(RA) S0 | L(RA+1) S1 | ...: behind L(u) lie the
+    //   stores of units u - RA .. u - 1 and the loads of units u + 1 .. u + RA.
+    constexpr int RA = EOVAE_Q16_RES_AHEAD;
+    f32x4 rv[RA + 1][4];
+    auto load_res = [&](f32x4 (&r)[4], int u) __attribute__((always_inline)) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * (u & 1) + jj;
+        if constexpr (RES) load128_asm(r[jj], rsrd, lot, (u >> 1) * tile16 + (j >> 1) * rowb + (j & 1) * 64);
+        else r[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    static_for<0, RA>([&](auto uc) __attribute__((always_inline)) { load_res(rv[decltype(uc)::value], decltype(uc)::value); });
+    float pv[2][4][4];
+    auto perm_issue = [&](float (&d)[4][4], int u) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = acc[u >> 1][4 * (u & 1) + j][k];   // (copied out: hipcc 7.2's __builtin_bit_cast of a vector ELEMENT expression reads element 0)
+          if (EOVAE_EPI_QUADS && !(EOVAE_Q16_ABL & 8)) bpermute_asm(d[j][k], psrc, a0);
+          else d[j][k] = a0;
+        }
+    };
+    perm_issue(pv[0], 0);
+    float sv = 0.f, qv = 0.f;
+    static_for<0, 16>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value, i = u >> 1, hf = u & 1;
+      wait_lgkm<0>();
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) landed(pv[u & 1][j][k]);
+      if constexpr (u + 1 < 16) perm_issue(pv[(u + 1) & 1], u + 1);
+      if constexpr (u + RA < 16) load_res(rv[(u + RA) % (RA + 1)], u + RA);
+      if constexpr (RES) {
+        wait_vm<4 * (u < RA ? u : RA) + 4 * ((u + RA < 15 ? u + RA : 15) - u)>();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) landed(rv[u % (RA + 1)][jj]);
+      } else if constexpr (u == 0) {
+        wait_vm<0>();
+      }
+      if constexpr (u == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) landed(bv[k]);
+      }
+      if constexpr (hf == 0) {
+        sv = 0.f;
+        qv = 0.f;
+      }
+      const float bias1 = bv[i];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(pv[u & 1][jj][k], xinv, bias1) + rv[u % (RA + 1)][jj][k];
+        finish(o, sv, qv, i, 4 * hf + jj);
+      }
+      if constexpr (hf == 1) {
+        cell[16 * i] = sv;
+        cell[4 * QBM + 16 * i] = qv;
+      }
     });
   };
 

@@ -22,9 +22,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 using lds_ptr = __attribute__((address_space(3))) void*;
 
+#ifndef EOVAE_Q16_RES_AHEAD
+#define EOVAE_Q16_RES_AHEAD 3   // conv_f16c8_q16.hip epilogue: residual loads requested this many half co tiles ahead
+#endif
 #ifndef EOVAE_Q16_ABL
 #define EOVAE_Q16_ABL 0   // timing-only experiments (WRONG results): 1 no s_nop in front of the correction MFMAs, 2 no output stores,
-                          // 4 every tile of a block stored to the same place (the output stays in the caches)
+                          // 4 every tile of a block stored to the same place (the output stays in the caches), 8 no lane permutation in
+                          // the epilogue, 16 no GroupNorm sums
 #endif
 typedef int i32x3 __attribute__((ext_vector_type(3)));
 template <int OFF>
