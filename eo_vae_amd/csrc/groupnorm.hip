@@ -677,6 +677,13 @@ __device__ __forceinline__ void gnf_st(float* p, const float4& o) {
 // s: partial sums published, waiting for its team), Q (slab s + 1: being summed) and N (slab s + 2: loads in flight).
 // The workgroup publishes slab s + 1 BEFORE it waits for slab s, so the hand-off latency of a slab is covered by the
 // arithmetic of the next one.  Same granules, tickets, tokens, partial layout and finalize kernel.
+// Round 6: the per-slab chain of DEPENDENT memory round trips is taken out of the iteration -- the kernel ran at "8.3 TB/s
+// plus 1.45 ps per element", i.e. ~4.6 us of fixed latency per slab (profiles/r06q_gn_bwd_nosync.log: the skip-gradient form
+// moves a third more bytes in 15 % more time).  (i) a slab's scalars (mean, rstd, the slice's gamma / beta) are requested
+// with its x / dy, one stage ahead, not at the head of its stage; (ii) the granule's gamma factor comes from those
+// registers, not from another load in front of the publishing store; (iii) the team's granules of slab s -- published one
+// iteration ago -- are REQUESTED before the arithmetic of slab s + 1 and only looked at behind it (the bounded poll loop
+// remains as the fallback for a granule that was not there yet); (iv) rstd of the waiting slab stays in a register.
 template <bool SILU, bool ADD, int V>
 __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_kernel(GnBwdFArgs a) {
   constexpr int SE = V * GNF_UNIT;
@@ -687,13 +694,20 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
   __shared__ unsigned ticket_s;
   if (tid == 0) ticket_s = atomicAdd(a.ticket, 1u) % gridDim.x;
   __syncthreads();
-  const int bid = (int)ticket_s;
+  // (readfirstlane: the id is uniform, and everything derived from it -- slab, channel, the scalars' addresses -- then lives
+  // in scalar registers and is fetched by scalar loads)
+  const int bid = __builtin_amdgcn_readfirstlane((int)ticket_s);
   const unsigned long long token = gnf_token(a);
   const int team = bid / a.T, member = bid % a.T;
   const size_t slab = (size_t)a.cpg * a.HW;
   float4 xp[V], dp[V], xq[V], dq[V], xn[V], dn[V], ar[V];
+  float mean_n = 0.f, rstd_n = 0.f, gm_n[V], bt_n[V];   // scalars of the slab whose loads are in flight
+  float rstd_q = 0.f, rstd_p = 0.f;
   float amax = 0.f;
 
+  // In THIS kernel a granule carries the launch's token advanced by its slab: the early request below lands in a register that
+  // still holds the previous slab's granule (same launch, same token) if the request's result were ever lost to a spill.
+  auto slab_token = [&](int s) { return token + (unsigned long long)(s + 1) * 0xD1B54A32D192ED03ull; };
   auto slice_ptr = [&](const float* p, int s) { return p + (size_t)s * slab + (size_t)member * SE + 4 * tid; };
   auto prefetch = [&](int s) __attribute__((always_inline)) {
     if (s < a.NG) {
@@ -704,20 +718,36 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
         xn[v] = gnf_ld(px + v * GNF_UNIT);
         dn[v] = gnf_ld(pd + v * GNF_UNIT);
       }
+      // (constant address space: nothing in this kernel writes stats / gamma / beta, and only that lets the compiler fetch
+      // the uniform values by SCALAR loads into scalar registers -- as plain global pointers they were vector loads held
+      // in 10 vector registers per set)
+      typedef const __attribute__((address_space(4))) float* cptr;
+      const cptr stats_c = (cptr)a.stats, gamma_c = (cptr)a.gamma, beta_c = (cptr)a.beta;
+      const int g = s % a.G;
+      mean_n = stats_c[2 * s];
+      rstd_n = stats_c[2 * s + 1];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c = g * a.cpg + (member * SE + v * GNF_UNIT) / a.HW;   // uniform: UNIT divides HW
+        gm_n[v] = gamma_c[c];
+        bt_n[v] = beta_c[c];
+      }
     }
   };
   // Q <- N, sum slab s in Q (Q then holds A = rstd gamma dz, B = rstd xhat), publish this member's granule
   auto stage = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
     for (int v = 0; v < V; ++v) { xq[v] = xn[v]; dq[v] = dn[v]; }
+    const float mean = mean_n, rstd = rstd_n;
+    float gm_q[V], bt_q[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { gm_q[v] = gm_n[v]; bt_q[v] = bt_n[v]; }
+    rstd_q = rstd;
     prefetch(s + a.nteams);
-    const int g = s % a.G;
-    const float mean = a.stats[2 * s], rstd = a.stats[2 * s + 1];
     float ps1[V], ps2[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int c = g * a.cpg + (member * SE + v * GNF_UNIT) / a.HW;
-      const float gm = a.gamma[c], bt = a.beta[c];
+      const float gm = gm_q[v], bt = bt_q[v];
       float s1 = 0.f, s2 = 0.f;
       auto term = [&](float& xv, float& dv) __attribute__((always_inline)) {
         const float xh = (xv - mean) * rstd;
@@ -744,22 +774,37 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
     }
     __syncthreads();
     if (wave == 0) {
+      // (the lane number re-derived here: the address a.part + lane is loop-invariant to the compiler, which hoisted it,
+      // spilled it and reloaded it right here -- behind an s_waitcnt vmcnt(0) that held the PUBLICATION until the next
+      // slab's x / dy had landed)
+      int fl;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(fl));
       double t1 = 0, t2 = 0;
-      if (lane < V) {
+      if (fl < V) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { t1 += red[w][2 * lane]; t2 += red[w][2 * lane + 1]; }
-        a.part[(size_t)s * a.T * V + member * V + lane] = make_float2((float)t1, (float)t2);
-        const float gmv = a.gamma[g * a.cpg + (member * SE + lane * GNF_UNIT) / a.HW];
+        for (int w = 0; w < NW; ++w) { t1 += red[w][2 * fl]; t2 += red[w][2 * fl + 1]; }
+        a.part[(size_t)s * a.T * V + member * V + fl] = make_float2((float)t1, (float)t2);
+        float gmv = gm_q[0];   // gamma of unit `lane`
+#pragma unroll
+        for (int v = 1; v < V; ++v) gmv = fl == v ? gm_q[v] : gmv;
         t1 *= gmv;
         t2 *= gmv;
       }
       t1 = wave_sum_d(t1);
       t2 = wave_sum_d(t2);
-      if (lane == 0) granule_store(a.team + (size_t)s * a.T + member, (float)t1, (float)t2, token);
+      if (fl == 0) granule_store(a.team + (size_t)s * a.T + member, (float)t1, (float)t2, slab_token(s));
     }
   };
-  // wait for slab s' team, then write dx of slab s from P
-  auto finish = [&](int s) __attribute__((always_inline)) {
+  // the team's granules of slab s, first 64 members: requested (wave 0) without a wait ...
+  i32x4 gv0;
+  auto team_request = [&](int s) __attribute__((always_inline)) {
+    if (wave == 0 && !EOVAE_GN_NOSYNC) {
+      const i32x4* p = a.team + (size_t)s * a.T + (lane < a.T ? lane : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(gv0) : "v"(p) : "memory");
+    }
+  };
+  // ... waited for, checked, then write dx of slab s from P
+  auto finish = [&](int s, bool prefetched) __attribute__((always_inline)) {
     if (ADD) {
       const float* pa = slice_ptr(a.dx_add, s);
 #pragma unroll
@@ -767,15 +812,23 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
     }
     if (wave == 0) {
       const i32x4* tg = a.team + (size_t)s * a.T;
+      const unsigned long long stok = slab_token(s);
       double m1 = 0, m2 = 0;
       unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       bool late = false;
+      if (!EOVAE_GN_NOSYNC) {
+        // team_request's load only: the vector loads issued behind it -- the next slab's 2 V (when stage() prefetched one)
+        // and the skip gradient's V -- stay in flight
+        if (prefetched) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * V + (ADD ? V : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ADD ? V : 0) : "memory");
+        asm volatile("" : "+v"(gv0));
+      }
       for (int j = lane; j < (EOVAE_GN_NOSYNC ? 0 : a.T); j += 64) {
-        i32x4 gv;
-        for (;;) {
-          gv = granule_load(tg + j);
+        i32x4 gv = gv0;
+        for (bool first = j == lane;; first = false) {
+          if (!first) gv = granule_load(tg + j);
           const unsigned long long tk = (unsigned long long)(unsigned)gv[2] | ((unsigned long long)(unsigned)gv[3] << 32);
-          if (tk == token) break;
+          if (tk == stok) break;
           if (gnf_timed_out(t0, a.err)) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
@@ -791,7 +844,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       }
     }
     __syncthreads();
-    const float k1 = a.stats[2 * s + 1] * gmean[0], m2f = gmean[1];
+    const float k1 = rstd_p * gmean[0], m2f = gmean[1];
     float* po = a.dx + (size_t)s * slab + (size_t)member * SE + 4 * tid;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -813,9 +866,11 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
     for (;;) {
 #pragma unroll
       for (int v = 0; v < V; ++v) { xp[v] = xq[v]; dp[v] = dq[v]; }
+      rstd_p = rstd_q;
       const int sn = s + a.nteams;
+      team_request(s);
       if (sn < a.NG) stage(sn);       // uniform
-      finish(s);
+      finish(s, sn < a.NG && sn + a.nteams < a.NG);
       if (sn >= a.NG) break;
       s = sn;
     }
