@@ -70,10 +70,29 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// (round 6) fp64: four DPP exchanges inside the 16-lane rows (lane ^ 1, lane ^ 2, mirror of 8, mirror of 16 -- every lane of
+// a row then holds the row's sum), the four row sums through v_readlane.  The __shfl_xor form was twelve ds_bpermute_b32 in six
+// DEPENDENT LDS round trips (~700 cycles of latency per call; the one-pass GroupNorm backward makes three such calls in a
+// row per slab).  Same value in every lane, fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_d(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move_d<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_move_d<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_move_d<0x141>(v);   // row_half_mirror: the other quad of the octet
+  v += dpp_move_d<0x140>(v);   // row_mirror: the other octet of the row
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
   constexpr int SE = V * GNF_UNIT;
   constexpr int NW = GNF_NT / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  __shared__ double red[NW][2 * V];
+  __shared__ double red[2][NW][2 * V];   // by stage parity: the next stage's writes cannot meet wave 0's reads of this one
   __shared__ float gmean[2];
   __shared__ unsigned ticket_s;
   if (tid == 0) ticket_s = atomicAdd(a.ticket, 1u) % gridDim.x;
@@ -704,6 +704,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
   float mean_n = 0.f, rstd_n = 0.f, gm_n[V], bt_n[V];   // scalars of the slab whose loads are in flight
   float rstd_q = 0.f, rstd_p = 0.f;
   float amax = 0.f;
+  int par = 0;
 
   // In THIS kernel a granule carries the launch's token advanced by its slab: the early request below lands in a register that
   // still holds the previous slab's granule (same launch, same token) if the request's result were ever lost to a spill.
@@ -766,11 +767,12 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       ps1[v] = s1;
       ps2[v] = s2;
     }
-    __syncthreads();   // red[] of the previous stage has been read
+    double (&rd)[NW][2 * V] = red[par];
+    par ^= 1;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const double d1 = wave_sum_d((double)ps1[v]), d2 = wave_sum_d((double)ps2[v]);
-      if (lane == 0) { red[wave][2 * v] = d1; red[wave][2 * v + 1] = d2; }
+      if (lane == 0) { rd[wave][2 * v] = d1; rd[wave][2 * v + 1] = d2; }
     }
     __syncthreads();
     if (wave == 0) {
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(GNF_NT, gnf_wg_per_cu(V)) void gn_bwd_fused_pipe_ke
       double t1 = 0, t2 = 0;
       if (fl < V) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { t1 += red[w][2 * fl]; t2 += red[w][2 * fl + 1]; }
+        for (int w = 0; w < NW; ++w) { t1 += rd[w][2 * fl]; t2 += rd[w][2 * fl + 1]; }
         a.part[(size_t)s * a.T * V + member * V + fl] = make_float2((float)t1, (float)t2);
         float gmv = gm_q[0];   // gamma of unit `lane`
 #pragma unroll
