@@ -490,10 +490,14 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv3x3_f16c8_w4_kernel(
   };
   // Round 6 (tools/probe_store_pattern.hip, profiles/r06o_*): the memory pipeline takes a wave's 16-byte accesses one QUAD of
   // consecutive lanes at a time, and the transposed layout above -- a quad = four CHANNELS -- costs it four lines per quad
-  // (16 bytes per clock and CU against 38..40 for a quad that covers one 64-byte segment).  Each transposed register
-  // therefore goes through one ds_bpermute_b32 (crossbar only): lane 32 h + 8 m + pq takes the value of lane
-  // 32 h + 4 pq + m and owns channel 8 qq + 4 h + m at pixels 4 pq .. 4 pq + 3 -- a quad = 64 consecutive bytes of one
-  // channel row.  Bias, residual and statistics run in that layout.
+  // (16 bytes per clock and CU against 38..40 for a quad that covers one 64-byte segment): THAT is the "one instruction
+  // per ~20 cycles whatever its width" above.  The 16-row form (NI = 4, the one that ships) therefore transposes each
+  // accumulator block through the wave's 4 KB of LDS instead (see the loop body): lane 32 h + 8 m + pq owns channel
+  // 8 qq + 4 h + m at pixels 4 pq .. 4 pq + 3 -- eight lanes = one 128-byte channel row -- and the ~20 VALU instructions per
+  // 16 values of the DPP transposition are gone (-6 / -4 / -2.4 % per layer at 128 / 256 / 512 channels,
+  // profiles/r06o_w4_epilogue_ab.log).  The parked 8-row form has no LDS left for that: it keeps the DPP transposition
+  // and passes each register through one ds_bpermute_b32 (lane 32 h + 8 m + pq <- lane 32 h + 4 pq + m) to get the same
+  // lane order.  Bias, residual and statistics run in that layout.
   // Every vector-memory instruction of the epilogue is an asm statement with hand-counted waits (the compiler does not
   // count asm stores, so its waits for builtin residual loads drained the stores in front of them), a layer without a
   // residual issues no residual loads (they were 64 zero-range loads per wave), and the per-lane addresses derive from
