@@ -82,7 +82,8 @@ __device__ unsigned long long w4_stamps[W4_NBLK * 4 * W4_MAXREC * W4_NPT];
 
 // NI = pixel rows per wave: 4 (16-row tiles, one block per CU, 512 registers per wave) or 2 (8-row tiles, TWO blocks
 // per CU with 256 registers per wave, started half a tile apart so that one block's epilogue -- which is bound by the
-// bytes a CU can move, ~13 B/clk, whatever the instruction width -- runs beside the other block's MFMAs).
+// bytes a CU can move, ~13 B/clk, whatever the instruction width (as measured in round 4; round 6 found why: the memory
+// pipeline's lane-quad rule, see the epilogue) -- runs beside the other block's MFMAs).
 // MX (round 5): the correction product on block-scaled FP6 operands (conv_f16c8_common.h) -- phases 9..17 run 16 x
 // v_mfma_scale_f32_32x32x64_f8f6f4 with e2m3 operands (~0.6 x the cycles of the fp8 form), each lane's scale byte riding in
 // dword 6 of its fragment.  Same LDS images, same fragment reads (the 32 FP6 bytes of a lane = 24 data + scale + pad sit
